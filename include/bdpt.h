@@ -1,0 +1,210 @@
+/*
+ * bdpt.h -- C-ABI of the MI355X bidirectional path tracer.
+ *
+ * The reference has no plugin or FFI layer: its device boundary is the literal
+ * sequence of OpenCL calls in src/renderer/main.cpp.  Each entry point below
+ * replaces one group of those calls (cited per function).  Plain pointers and
+ * sizes only; every function returns BDPT_OK (0) or a negative bdpt_status and
+ * records a message readable through bdpt_last_error().
+ *
+ * Threading: a context is bound to one GPU and is not re-entrant; use one
+ * context per device (one process per GPU in the multi-GPU drivers).
+ *
+ * Image layout: every per-pixel buffer that crosses this boundary is row-major,
+ * pixel (x, y) at index y*width + x, except the seed buffer, which keeps the
+ * reference's column-major index x*height + y (kernel0.cl:590, :861).
+ */
+#ifndef BDPT_H
+#define BDPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bdpt_status {
+    BDPT_OK = 0,
+    BDPT_ERR_INVALID = -1,   /* bad argument */
+    BDPT_ERR_HIP = -2,       /* a HIP runtime call failed */
+    BDPT_ERR_STATE = -3,     /* call out of order (e.g. render before upload) */
+    BDPT_ERR_NO_DEVICE = -4  /* no usable GPU / ordinal out of range */
+} bdpt_status;
+
+/* ---- upload structs: byte-for-byte the reference's host structs ---------- */
+
+/* src/include/geometry/primitives.h:6-17 (32 B); kernel view kernel0.cl:32-38 */
+typedef struct bdpt_sphere {
+    float center[4];
+    float radius;
+    uint32_t surface;
+    uint32_t reserved0, reserved1;
+} bdpt_sphere;
+
+/* primitives.h:19-32 (64 B); kernel view kernel0.cl:72-79 (p0,p1,p2 = a,b,c) */
+typedef struct bdpt_triangle {
+    float p0[4], p1[4], p2[4];
+    uint32_t surface;
+    uint32_t reserved0, reserved1, reserved2;
+} bdpt_triangle;
+
+/* primitives.h:34-46 (48 B); kernel view kernel0.cl:81-86 */
+typedef struct bdpt_plane {
+    float normal[4];
+    float point[4];
+    uint32_t surface;
+    uint32_t reserved0, reserved1, reserved2;
+} bdpt_plane;
+
+/* primitives.h:57-64 (32 B); kernel view kernel0.cl:90-94 */
+typedef struct bdpt_surface {
+    float color[4];
+    float emissive[4];   /* emissive[3] != 0 marks a light (kernel0.cl:645, :797) */
+} bdpt_surface;
+
+/* src/include/renderer/camera.h:37-41 (48 B); look_at is a DIRECTION (camera.cpp:47) */
+typedef struct bdpt_camera {
+    float pos[4];
+    float look_at[4];
+    float up[4];
+} bdpt_camera;
+
+/* ---- parameters that are macros / literals in the reference -------------- */
+
+enum { BDPT_RNG_STREAM = 0, BDPT_RNG_STRIDED = 1 };
+enum { BDPT_LIGHT_ORIGIN_SELF = 0, BDPT_LIGHT_ORIGIN_NONE = 1 };
+enum { BDPT_FALLOFF_INV_SQ = 0, BDPT_FALLOFF_INV_SQ_PLUS_C = 1 };
+enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_WAVEFRONT = 2 };
+
+typedef struct bdpt_params {
+    int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */
+    float p_continue;           /* pCon, kernel0.cl:687 (0.8f) */
+    float blur_factor;          /* BLUR_FACTOR, kernel0.cl:13 (2.0f) */
+    int32_t indirect_only;      /* INDIRECT_ONLY, kernel0.cl:11, :752-754, :843-847 (0) */
+    int32_t light_index;        /* lIndex, kernel0.cl:663 (sphere 0) */
+    /* BDPT_RNG_STREAM: the reference's sequential per-pixel LCG, including its
+     * behaviour on early-out samples (no seed write-back, raw value written).
+     * BDPT_RNG_STRIDED: sample s of a pixel starts at seed * 48271^(32*s), so
+     * any rank can render any sample range; early-outs are ordinary samples. */
+    int32_t rng_mode;
+    /* Which primitive the first light-subpath rays skip.  The reference reads
+     * an uninitialised id here (kernel0.cl:547-569, :675, :705); SELF = the
+     * emitting sphere (0, light_index), NONE = no primitive is skipped. */
+    int32_t light_origin;
+    int32_t connection_falloff; /* kernel0.cl:719 is 1/r^2 (INV_SQ) */
+    float falloff_c;            /* c of 1/(c + r^2) when INV_SQ_PLUS_C */
+    /* MEAN: running mean prev*n/(n+1) + new/(n+1) (kernel0.cl:853-856).
+     * SUM: plain sum of samples, for combining partial images across GPUs. */
+    int32_t accum_mode;
+    int32_t aov_enable;         /* maintain the bdpt_read_aov() buffers */
+    int32_t kernel_variant;     /* BDPT_KERNEL_*; AUTO picks by scene size */
+} bdpt_params;
+
+typedef struct bdpt_ctx bdpt_ctx;
+
+/* ---- context: replaces cl::Context / devices / cl::CommandQueue
+ *      (main.cpp:227-260, :462-466, :522) and the two W x H images (:265-268,
+ *      :448-452).  The HIP code object is linked into the library, so there is
+ *      no counterpart of the run-time program build (main.cpp:468-484). */
+int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out);
+void bdpt_destroy(bdpt_ctx *ctx);
+const char *bdpt_version(void);
+/* checkErr (main.cpp:41-46) printed and exited; here the caller decides. */
+const char *bdpt_last_error(const bdpt_ctx *ctx);
+
+/* Fills *p with the reference's literals (see the field comments). */
+void bdpt_default_params(bdpt_params *p);
+int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p);
+int bdpt_get_params(const bdpt_ctx *ctx, bdpt_params *p);
+
+/* cl::Buffer creation + blocking enqueueWriteBuffer of spheres, planes,
+ * triangles, GeometryDescriptor and surfaces (main.cpp:424-446, :534-539).
+ * The arrays are copied and re-laid out before return; null pointers are
+ * allowed for zero counts.  Resets the sample counter. */
+int bdpt_upload_scene(bdpt_ctx *ctx,
+                      const bdpt_sphere *spheres, int n_spheres,
+                      const bdpt_plane *planes, int n_planes,
+                      const bdpt_triangle *triangles, int n_triangles,
+                      const bdpt_surface *surfaces, int n_surfaces);
+
+/* Seed upload (main.cpp:456-460, :538): width*height uint4, index x*height+y;
+ * only .w drives the generator (kernel0.cl:106-109). */
+int bdpt_upload_seeds(bdpt_ctx *ctx, const uint32_t *seeds);
+int bdpt_read_seeds(bdpt_ctx *ctx, uint32_t *seeds);
+
+/* Camera upload; like the reference it also zeroes the sample counter
+ * (main.cpp:150-156, :524-533). */
+int bdpt_set_camera(bdpt_ctx *ctx, const bdpt_camera *cam);
+
+/* ImageDescriptor write + kernel launch + wait + numSamples += spp
+ * (main.cpp:108-131), for `spp` consecutive samples per pixel in one launch.
+ * The accumulator is updated in place (the reference's out->in blit,
+ * main.cpp:133-138).  bdpt_render waits; bdpt_render_async only enqueues. */
+int bdpt_render(bdpt_ctx *ctx, int spp);
+int bdpt_render_async(bdpt_ctx *ctx, int spp);
+int bdpt_sync(bdpt_ctx *ctx);
+int bdpt_num_samples(const bdpt_ctx *ctx);
+/* Sets the sample counter (imgDesc.numSamples, main.cpp:152, :546). */
+int bdpt_set_num_samples(bdpt_ctx *ctx, int n);
+
+/* Read-back of the accumulated image, width*height RGBA float, row-major
+ * (stands in for the present blit, main.cpp:140-145). */
+int bdpt_read_accum(bdpt_ctx *ctx, float *rgba);
+
+/* ---- additions with no reference counterpart ----------------------------- */
+
+/* Multi-GPU partitioning.  Region: only pixels inside the rectangle are
+ * rendered (image-tile split).  Sample offset: in STRIDED mode the first
+ * sample index this context renders after a camera reset (spp split). */
+int bdpt_set_region(bdpt_ctx *ctx, int x0, int y0, int w, int h);
+int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample);
+
+/* Interop with a caller that owns device memory and streams (torch):
+ * render on `hip_stream` (NULL = the context's own stream), and accumulate into
+ * caller-owned device memory of width*height*4 floats (NULL = internal). */
+int bdpt_set_stream(bdpt_ctx *ctx, void *hip_stream);
+int bdpt_bind_accum(bdpt_ctx *ctx, void *device_rgba);
+void *bdpt_accum_device_ptr(bdpt_ctx *ctx);
+
+/* Parity / accounting outputs, maintained when params.aov_enable != 0 and
+ * cleared by bdpt_set_camera / bdpt_upload_scene / bdpt_upload_seeds. */
+enum {
+    BDPT_AOV_EYE_HIT = 0,   /* int32[2] per pixel: (type, index) of the last sample's eye hit, (-1,-1) on a miss */
+    BDPT_AOV_HIT_HASH = 1,  /* uint32 per pixel: h = (h ^ id) * 16777619 over every closest-hit query, id = type<<28 | index, 0xFFFFFFFF on a miss */
+    BDPT_AOV_RADIANCE = 2,  /* float[4] per pixel: the last sample's value before accumulation */
+    BDPT_AOV_RNG_DRAWS = 3, /* uint32 per pixel: generator draws since reset */
+    BDPT_AOV_RAYS = 4       /* uint32 per pixel: closest-hit queries since reset */
+};
+int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out);
+
+/* Work counters of the most recent render call that was made with
+ * counting on: out[0] closest-hit queries, out[1] samples that reached the
+ * light loop, out[2] samples that ended at the eye ray.  Counting adds device
+ * atomics, so it is off unless enabled here. */
+int bdpt_enable_counters(bdpt_ctx *ctx, int on);
+int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[3]);
+
+/* Closest hit (ray_intersect, kernel0.cl:365-478) of n caller-supplied rays
+ * against the uploaded scene, on the GPU.  rays: 6 floats per ray (origin xyz,
+ * direction xyz); origin_ids: 2 ints per ray, the (type, index) of the
+ * primitive the ray leaves and must skip, (4, 0) for none.  out_ids: 2 ints per
+ * ray, (-1,-1) on a miss; out_pos / out_normal: 3 floats per ray.  Host
+ * pointers; returns after the results are copied back. */
+int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n,
+                    int32_t *out_ids, float *out_pos, float *out_normal);
+
+/* Evaluates one built-in of the numeric contract (include/bdpt_clmath.h) on the
+ * GPU for n inputs of 3 doubles each: op 0 sin, 1 cos, 2 acos(float),
+ * 3 acos(double), 4 sqrt, 5 a/b, 6 fma(a,b,c), 7 x of normalize(a,b,c).
+ * For checking that device and host arithmetic agree bit for bit. */
+int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n);
+
+/* Device time of the most recent render launch in milliseconds (HIP events on
+ * the stream the kernel ran on); waits for that launch. */
+int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDPT_H */

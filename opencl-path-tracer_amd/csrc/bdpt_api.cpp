@@ -1,0 +1,604 @@
+/*
+ * bdpt_api.cpp -- the C-ABI of include/bdpt.h over the HIP runtime.
+ *
+ * Replaces the OpenCL buffer / queue / kernel plumbing that the reference does
+ * inline in src/renderer/main.cpp (:227-260 context, :424-452 buffers, :489-509
+ * kernel arguments, :533-539 uploads, :100-172 per-frame launch).  There is no
+ * CPU fallback: without a GPU every entry point that needs one fails.
+ *
+ * Built with -ffp-contract=off: the scene pre-processing below evaluates the
+ * ray-independent parts of the reference's primitive tests on the host with the
+ * numeric contract, and the device consumes the results as they are.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bdpt.h"
+#include "../../include/bdpt_clmath.h"
+#include "bdpt_kernels.h"
+#include "bdpt_layout.h"
+
+struct bdpt_ctx {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool have_launch = false;
+
+    bdpt_params params{};
+    bdpt_camera camera{};
+    bool have_camera = false, have_scene = false, have_seeds = false;
+    int num_samples = 0;
+    int sample_offset = 0;
+    int rx0 = 0, ry0 = 0, rw = 0, rh = 0;
+    bool counters_on = false;
+
+    /* host copies needed after upload */
+    std::vector<bdpt_sphere> spheres;
+    std::vector<bdpt_surface> surfaces;
+    std::vector<uint32_t> seeds;       /* the caller's uint4 seeds, reference layout */
+    int n_planes = 0, n_triangles = 0;
+
+    /* device memory */
+    float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_surf = nullptr;
+    uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
+    uint32_t *d_seed_w = nullptr;
+    float4 *d_accum_own = nullptr;
+    float4 *d_accum = nullptr;
+    int32_t *d_aov_eye = nullptr;
+    uint32_t *d_aov_hash = nullptr, *d_aov_draws = nullptr, *d_aov_rays = nullptr;
+    float4 *d_aov_rad = nullptr;
+    unsigned long long *d_counters = nullptr;
+
+    std::string err;
+};
+
+static thread_local std::string g_null_ctx_error;
+
+static int fail(bdpt_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    else g_null_ctx_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, BDPT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+template <class T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+template <class T>
+static hipError_t dev_upload(T *&dst, const std::vector<T> &src)
+{
+    dev_free(dst);
+    /* keep a valid pointer even for empty arrays: kernels never dereference it then */
+    size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    hipError_t e = hipMalloc((void **)&dst, bytes);
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+static clm_f3 v3(const float *p) { return clm_make3(p[0], p[1], p[2]); }
+
+extern "C" {
+
+const char *bdpt_version(void) { return "bdpt-amd 0.1 (gfx950)"; }
+
+const char *bdpt_last_error(const bdpt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_null_ctx_error.c_str(); }
+
+void bdpt_default_params(bdpt_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->max_light_bounces = 5;
+    p->p_continue = 0.8f;
+    p->blur_factor = 2.0f;
+    p->indirect_only = 0;
+    p->light_index = 0;
+    p->rng_mode = BDPT_RNG_STREAM;
+    p->light_origin = BDPT_LIGHT_ORIGIN_SELF;
+    p->connection_falloff = BDPT_FALLOFF_INV_SQ;
+    p->falloff_c = 1.0f;
+    p->accum_mode = BDPT_ACCUM_MEAN;
+    p->aov_enable = 0;
+    p->kernel_variant = BDPT_KERNEL_AUTO;
+}
+
+int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
+{
+    if (!out) return fail(nullptr, BDPT_ERR_INVALID, "bdpt_create: out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1LL << 28))
+        return fail(nullptr, BDPT_ERR_INVALID, "bdpt_create: bad image size");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, BDPT_ERR_NO_DEVICE, "bdpt_create: no HIP device available (this library has no CPU path)");
+    if (device_ordinal < 0 || device_ordinal >= n_dev)
+        return fail(nullptr, BDPT_ERR_NO_DEVICE, "bdpt_create: device ordinal out of range");
+
+    bdpt_ctx *ctx = new bdpt_ctx();
+    ctx->device = device_ordinal;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->rw = width;
+    ctx->rh = height;
+    bdpt_default_params(&ctx->params);
+    const size_t npix = (size_t)width * height;
+    auto bail = [&](hipError_t err, const char *what) {
+        std::string msg = std::string("bdpt_create: ") + what + ": " + hipGetErrorString(err);
+        bdpt_destroy(ctx);
+        return fail(nullptr, BDPT_ERR_HIP, msg);
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreate(&ctx->own_stream)) != hipSuccess) return bail(e, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc((void **)&ctx->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accum");
+    if ((e = hipMemset(ctx->d_accum_own, 0, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMemset accum");
+    ctx->d_accum = ctx->d_accum_own;
+    if ((e = hipMalloc((void **)&ctx->d_seed_w, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc seeds");
+    if ((e = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counters");
+    if ((e = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset counters");
+    *out = ctx;
+    return BDPT_OK;
+}
+
+void bdpt_destroy(bdpt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_surf);
+    dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
+    dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
+    dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
+    dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+static int reset_aovs(bdpt_ctx *ctx)
+{
+    if (!ctx->d_aov_hash) return BDPT_OK;
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov_eye, 0xFF, npix * 2 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov_hash, 0, npix * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov_draws, 0, npix * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov_rays, 0, npix * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov_rad, 0, npix * sizeof(float4), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDPT_OK;
+}
+
+static int ensure_aovs(bdpt_ctx *ctx)
+{
+    if (ctx->d_aov_hash) return BDPT_OK;
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_eye, npix * 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_draws, npix * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_rays, npix * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_rad, npix * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_hash, npix * sizeof(uint32_t)));
+    return reset_aovs(ctx);
+}
+
+int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
+{
+    if (!ctx || !p) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: null argument");
+    if (p->max_light_bounces < 1 || p->max_light_bounces > 64)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: max_light_bounces must be in [1, 64]");
+    if (!(p->p_continue > 0.0f) || !(p->p_continue < 1.0f))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: p_continue must be in (0, 1)");
+    if (!(p->blur_factor >= 0.0f)) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: blur_factor must be >= 0");
+    if (p->light_index < 0) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: light_index must be >= 0");
+    if (p->rng_mode != BDPT_RNG_STREAM && p->rng_mode != BDPT_RNG_STRIDED)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown rng_mode");
+    if (p->light_origin != BDPT_LIGHT_ORIGIN_SELF && p->light_origin != BDPT_LIGHT_ORIGIN_NONE)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown light_origin");
+    if (p->connection_falloff != BDPT_FALLOFF_INV_SQ && p->connection_falloff != BDPT_FALLOFF_INV_SQ_PLUS_C)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown connection_falloff");
+    if (p->accum_mode != BDPT_ACCUM_MEAN && p->accum_mode != BDPT_ACCUM_SUM)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
+    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_WAVEFRONT)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->params = *p;
+    if (p->aov_enable) return ensure_aovs(ctx);
+    return BDPT_OK;
+}
+
+int bdpt_get_params(const bdpt_ctx *ctx, bdpt_params *p)
+{
+    if (!ctx || !p) return BDPT_ERR_INVALID;
+    *p = ctx->params;
+    return BDPT_OK;
+}
+
+int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, const bdpt_plane *planes, int n_planes,
+                      const bdpt_triangle *triangles, int n_triangles, const bdpt_surface *surfaces, int n_surfaces)
+{
+    if (!ctx) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: null context");
+    if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || n_surfaces <= 0)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: negative count or no surfaces");
+    if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || !surfaces)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: null array with non-zero count");
+    if (n_spheres >= (1 << 28) || n_planes >= (1 << 28) || n_triangles >= (1 << 28))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: too many primitives");
+    /* a surface id outside the table would be an out-of-bounds read on the device */
+    for (int i = 0; i < n_spheres; i++)
+        if (spheres[i].surface >= (uint32_t)n_surfaces) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: sphere surface id out of range");
+    for (int i = 0; i < n_planes; i++)
+        if (planes[i].surface >= (uint32_t)n_surfaces) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: plane surface id out of range");
+    for (int i = 0; i < n_triangles; i++)
+        if (triangles[i].surface >= (uint32_t)n_surfaces) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: triangle surface id out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4), tri((size_t)n_triangles * BDPT_TRI_F4),
+        surf((size_t)n_surfaces * 2);
+    std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
+    for (int i = 0; i < n_spheres; i++) {
+        const bdpt_sphere &s = spheres[i];
+        sph[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);   /* kernel0.cl:337 */
+        sph_s[i] = s.surface;
+    }
+    for (int i = 0; i < n_planes; i++) {
+        const bdpt_plane &p = planes[i];
+        pln[(size_t)i * 2 + 0] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.0f);
+        pln[(size_t)i * 2 + 1] = make_float4(p.point[0], p.point[1], p.point[2], 0.0f);
+        pln_s[i] = p.surface;
+    }
+    for (int i = 0; i < n_triangles; i++) {
+        const bdpt_triangle &t = triangles[i];
+        const clm_f3 a = v3(t.p0), b = v3(t.p1), c = v3(t.p2);
+        const clm_f3 e0 = clm_sub3(c, a), e1 = clm_sub3(b, c), e2 = clm_sub3(a, b);
+        const clm_f3 n = clm_normalize3(clm_cross3(clm_sub3(b, a), e0));                     /* kernel0.cl:285 */
+        const clm_f3 ns = clm_normalize3(clm_cross3(e2, e1));                                /* kernel0.cl:467 */
+        float4 *q = &tri[(size_t)i * BDPT_TRI_F4];
+        q[0] = make_float4(n.x, n.y, n.z, a.x);
+        q[1] = make_float4(a.y, a.z, e0.x, e0.y);
+        q[2] = make_float4(e0.z, c.x, c.y, c.z);
+        q[3] = make_float4(e1.x, e1.y, e1.z, b.x);
+        q[4] = make_float4(b.y, b.z, e2.x, e2.y);
+        q[5] = make_float4(e2.z, ns.x, ns.y, ns.z);
+        tri_s[i] = t.surface;
+    }
+    for (int i = 0; i < n_surfaces; i++) {
+        const bdpt_surface &s = surfaces[i];
+        surf[(size_t)i * 2 + 0] = make_float4(s.color[0], s.color[1], s.color[2], s.color[3]);
+        surf[(size_t)i * 2 + 1] = make_float4(s.emissive[0], s.emissive[1], s.emissive[2], s.emissive[3]);
+    }
+    HIP_TRY(ctx, dev_upload(ctx->d_sph, sph));
+    HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
+    HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
+    HIP_TRY(ctx, dev_upload(ctx->d_surf, surf));
+    HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
+    HIP_TRY(ctx, dev_upload(ctx->d_pln_surf, pln_s));
+    HIP_TRY(ctx, dev_upload(ctx->d_tri_surf, tri_s));
+    ctx->spheres.assign(spheres, spheres + n_spheres);
+    ctx->surfaces.assign(surfaces, surfaces + n_surfaces);
+    ctx->n_planes = n_planes;
+    ctx->n_triangles = n_triangles;
+    ctx->have_scene = true;
+    ctx->num_samples = 0;
+    return reset_aovs(ctx);
+}
+
+int bdpt_upload_seeds(bdpt_ctx *ctx, const uint32_t *seeds)
+{
+    if (!ctx || !seeds) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_seeds: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int W = ctx->width, H = ctx->height;
+    const size_t npix = (size_t)W * H;
+    ctx->seeds.assign(seeds, seeds + npix * 4);
+    std::vector<uint32_t> w(npix);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) w[(size_t)y * W + x] = seeds[((size_t)x * H + y) * 4 + 3];   /* kernel0.cl:590 */
+    HIP_TRY(ctx, hipMemcpy(ctx->d_seed_w, w.data(), npix * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->have_seeds = true;
+    return reset_aovs(ctx);
+}
+
+int bdpt_read_seeds(bdpt_ctx *ctx, uint32_t *seeds)
+{
+    if (!ctx || !seeds) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_seeds: null argument");
+    if (!ctx->have_seeds) return fail(ctx, BDPT_ERR_STATE, "bdpt_read_seeds: no seeds uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int W = ctx->width, H = ctx->height;
+    const size_t npix = (size_t)W * H;
+    std::vector<uint32_t> w(npix);
+    HIP_TRY(ctx, hipMemcpy(w.data(), ctx->d_seed_w, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) ctx->seeds[((size_t)x * H + y) * 4 + 3] = w[(size_t)y * W + x];
+    std::memcpy(seeds, ctx->seeds.data(), npix * 4 * sizeof(uint32_t));
+    return BDPT_OK;
+}
+
+int bdpt_set_camera(bdpt_ctx *ctx, const bdpt_camera *cam)
+{
+    if (!ctx || !cam) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_camera: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->camera = *cam;
+    ctx->have_camera = true;
+    ctx->num_samples = 0;                                                 /* main.cpp:152 */
+    return reset_aovs(ctx);
+}
+
+int bdpt_num_samples(const bdpt_ctx *ctx) { return ctx ? ctx->num_samples : BDPT_ERR_INVALID; }
+
+int bdpt_set_num_samples(bdpt_ctx *ctx, int n)
+{
+    if (!ctx || n < 0) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_num_samples: bad argument");
+    ctx->num_samples = n;
+    return BDPT_OK;
+}
+
+int bdpt_set_region(bdpt_ctx *ctx, int x0, int y0, int w, int h)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > ctx->width || y0 + h > ctx->height)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_region: rectangle outside the image");
+    ctx->rx0 = x0; ctx->ry0 = y0; ctx->rw = w; ctx->rh = h;
+    return BDPT_OK;
+}
+
+int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample)
+{
+    if (!ctx || first_sample < 0) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_sample_offset: bad argument");
+    ctx->sample_offset = first_sample;
+    return BDPT_OK;
+}
+
+int bdpt_set_stream(bdpt_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->have_launch = false;
+    return BDPT_OK;
+}
+
+int bdpt_bind_accum(bdpt_ctx *ctx, void *device_rgba)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (device_rgba && ((uintptr_t)device_rgba & 15u))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_bind_accum: pointer must be 16-byte aligned");
+    ctx->d_accum = device_rgba ? (float4 *)device_rgba : ctx->d_accum_own;
+    return BDPT_OK;
+}
+
+void *bdpt_accum_device_ptr(bdpt_ctx *ctx) { return ctx ? (void *)ctx->d_accum : nullptr; }
+
+int bdpt_enable_counters(bdpt_ctx *ctx, int on)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    ctx->counters_on = on != 0;
+    return BDPT_OK;
+}
+
+static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
+{
+    const bdpt_params &P = ctx->params;
+    if (!ctx->have_scene) return fail(ctx, BDPT_ERR_STATE, "bdpt_render: no scene uploaded");
+    if (!ctx->have_seeds) return fail(ctx, BDPT_ERR_STATE, "bdpt_render: no seeds uploaded");
+    if (!ctx->have_camera) return fail(ctx, BDPT_ERR_STATE, "bdpt_render: no camera set");
+    if (spp < 1 || spp > (1 << 24)) return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: spp must be in [1, 2^24]");
+    if (P.light_index >= (int)ctx->spheres.size())
+        return fail(ctx, BDPT_ERR_STATE, "bdpt_render: light_index is not a sphere of the uploaded scene");
+    std::memset(&K, 0, sizeof K);
+    K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
+    K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
+    K.scene.tri = ctx->d_tri; K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.surf = ctx->d_surf;
+    K.scene.n_spheres = (int)ctx->spheres.size();
+    K.scene.n_planes = ctx->n_planes;
+    K.scene.n_triangles = ctx->n_triangles;
+    K.scene.n_surfaces = (int)ctx->surfaces.size();
+    K.seed_w = ctx->d_seed_w;
+    K.accum = ctx->d_accum;
+    K.aov_eye_hit = ctx->d_aov_eye; K.aov_hit_hash = ctx->d_aov_hash; K.aov_radiance = ctx->d_aov_rad;
+    K.aov_rng_draws = ctx->d_aov_draws; K.aov_rays = ctx->d_aov_rays;
+    K.counters = ctx->d_counters;
+    K.width = ctx->width; K.height = ctx->height;
+    K.rx0 = ctx->rx0; K.ry0 = ctx->ry0; K.rw = ctx->rw; K.rh = ctx->rh;
+    K.num_samples = ctx->num_samples;
+    K.spp = spp;
+    K.first_sample = (uint32_t)(ctx->sample_offset + ctx->num_samples);
+
+    const bdpt_camera &C = ctx->camera;
+    const clm_f3 right = clm_cross3(v3(C.up), v3(C.look_at));            /* kernel0.cl:212 */
+    for (int k = 0; k < 3; k++) { K.cam_pos[k] = C.pos[k]; K.cam_look[k] = C.look_at[k]; K.cam_up[k] = C.up[k]; }
+    K.cam_right[0] = right.x; K.cam_right[1] = right.y; K.cam_right[2] = right.z;
+    K.aspect = clm_div((float)ctx->width * 1.0f, (float)ctx->height);   /* kernel0.cl:603 */
+    K.delta_x = clm_div(P.blur_factor, (float)ctx->width);               /* kernel0.cl:196 */
+    K.delta_y = clm_div(P.blur_factor, (float)ctx->height);              /* kernel0.cl:197 */
+
+    const bdpt_sphere &L = ctx->spheres[P.light_index];
+    for (int k = 0; k < 3; k++) K.light_c[k] = L.center[k];
+    K.light_r = L.radius;
+    for (int k = 0; k < 4; k++) K.light_emissive[k] = ctx->surfaces[L.surface].emissive[k];   /* kernel0.cl:563 */
+    if (P.light_origin == BDPT_LIGHT_ORIGIN_SELF) { K.light_origin_type = 0; K.light_origin_index = P.light_index; }
+    else { K.light_origin_type = -1; K.light_origin_index = -1; }
+
+    K.max_l = P.max_light_bounces;
+    K.p_con = P.p_continue;
+    K.pre_factor0 = clm_div(1.0f - P.p_continue, 1.0f - clm_powi(P.p_continue, P.max_light_bounces));   /* kernel0.cl:694 */
+    K.indirect_only = P.indirect_only;
+    K.rng_mode = P.rng_mode;
+    K.falloff = P.connection_falloff;
+    K.falloff_c = P.falloff_c;
+    K.accum_mode = P.accum_mode;
+    return BDPT_OK;
+}
+
+int bdpt_render_async(bdpt_ctx *ctx, int spp)
+{
+    if (!ctx) return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: null context");
+    bdpt_kargs K;
+    int rc = fill_kargs(ctx, spp, K);
+    if (rc != BDPT_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool aov = ctx->params.aov_enable != 0;
+    if (aov && (rc = ensure_aovs(ctx)) != BDPT_OK) return rc;
+    if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    ctx->have_launch = true;
+    ctx->num_samples += spp;                                              /* main.cpp:131 */
+    return BDPT_OK;
+}
+
+int bdpt_sync(bdpt_ctx *ctx)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDPT_OK;
+}
+
+int bdpt_render(bdpt_ctx *ctx, int spp)
+{
+    int rc = bdpt_render_async(ctx, spp);
+    if (rc != BDPT_OK) return rc;
+    return bdpt_sync(ctx);                                                /* main.cpp:121-124 */
+}
+
+int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return fail(ctx, BDPT_ERR_INVALID, "bdpt_last_launch_ms: null argument");
+    if (!ctx->have_launch) return fail(ctx, BDPT_ERR_STATE, "bdpt_last_launch_ms: nothing launched yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
+    return BDPT_OK;
+}
+
+int bdpt_read_accum(bdpt_ctx *ctx, float *rgba)
+{
+    if (!ctx || !rgba) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_accum: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(rgba, ctx->d_accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+    return BDPT_OK;
+}
+
+int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out)
+{
+    if (!ctx || !out) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_aov: null argument");
+    if (!ctx->d_aov_hash) return fail(ctx, BDPT_ERR_STATE, "bdpt_read_aov: params.aov_enable was never set");
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (kind) {
+    case BDPT_AOV_EYE_HIT: src = ctx->d_aov_eye; bytes = npix * 2 * sizeof(int32_t); break;
+    case BDPT_AOV_HIT_HASH: src = ctx->d_aov_hash; bytes = npix * sizeof(uint32_t); break;
+    case BDPT_AOV_RADIANCE: src = ctx->d_aov_rad; bytes = npix * sizeof(float4); break;
+    case BDPT_AOV_RNG_DRAWS: src = ctx->d_aov_draws; bytes = npix * sizeof(uint32_t); break;
+    case BDPT_AOV_RAYS: src = ctx->d_aov_rays; bytes = npix * sizeof(uint32_t); break;
+    default: return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_aov: unknown kind");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return BDPT_OK;
+}
+
+int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[3])
+{
+    if (!ctx || !out) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_counters: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c[3];
+    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    return BDPT_OK;
+}
+
+int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n, int32_t *out_ids, float *out_pos,
+                    float *out_normal)
+{
+    if (!ctx || n < 0 || (n && (!rays || !origin_ids || !out_ids || !out_pos || !out_normal)))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_query_rays: bad argument");
+    if (!ctx->have_scene) return fail(ctx, BDPT_ERR_STATE, "bdpt_query_rays: no scene uploaded");
+    if (n == 0) return BDPT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_rays = nullptr, *d_pos = nullptr, *d_n = nullptr;
+    int *d_org = nullptr, *d_id = nullptr;
+    int rc = BDPT_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == BDPT_OK) rc = fail(ctx, BDPT_ERR_HIP, std::string("bdpt_query_rays: ") + what + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    bdpt_dev_scene S{};
+    S.sph = ctx->d_sph; S.sph_surf = ctx->d_sph_surf; S.pln = ctx->d_pln; S.pln_surf = ctx->d_pln_surf;
+    S.tri = ctx->d_tri; S.tri_surf = ctx->d_tri_surf; S.surf = ctx->d_surf;
+    S.n_spheres = (int)ctx->spheres.size(); S.n_planes = ctx->n_planes; S.n_triangles = ctx->n_triangles;
+    S.n_surfaces = (int)ctx->surfaces.size();
+    const size_t N = (size_t)n;
+    if (step(hipMalloc((void **)&d_rays, N * 6 * sizeof(float)), "hipMalloc") &&
+        step(hipMalloc((void **)&d_org, N * 2 * sizeof(int)), "hipMalloc") &&
+        step(hipMalloc((void **)&d_id, N * 2 * sizeof(int)), "hipMalloc") &&
+        step(hipMalloc((void **)&d_pos, N * 3 * sizeof(float)), "hipMalloc") &&
+        step(hipMalloc((void **)&d_n, N * 3 * sizeof(float)), "hipMalloc") &&
+        step(hipMemcpy(d_rays, rays, N * 6 * sizeof(float), hipMemcpyHostToDevice), "copy rays") &&
+        step(hipMemcpy(d_org, origin_ids, N * 2 * sizeof(int), hipMemcpyHostToDevice), "copy origins") &&
+        step(bdpt_launch_query(S, d_rays, d_org, n, d_id, d_pos, d_n, ctx->stream), "launch") &&
+        step(hipStreamSynchronize(ctx->stream), "sync") &&
+        step(hipMemcpy(out_ids, d_id, N * 2 * sizeof(int), hipMemcpyDeviceToHost), "copy ids") &&
+        step(hipMemcpy(out_pos, d_pos, N * 3 * sizeof(float), hipMemcpyDeviceToHost), "copy pos")) {
+        step(hipMemcpy(out_normal, d_n, N * 3 * sizeof(float), hipMemcpyDeviceToHost), "copy normals");
+    }
+    dev_free(d_rays); dev_free(d_org); dev_free(d_id); dev_free(d_pos); dev_free(d_n);
+    return rc;
+}
+
+int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n)
+{
+    if (!ctx || n < 0 || op < 0 || op > 7 || (n && (!in || !out))) return fail(ctx, BDPT_ERR_INVALID, "bdpt_clmath_eval: bad argument");
+    if (n == 0) return BDPT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    int rc = BDPT_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == BDPT_OK) rc = fail(ctx, BDPT_ERR_HIP, std::string("bdpt_clmath_eval: ") + what + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    const size_t N = (size_t)n;
+    if (step(hipMalloc((void **)&d_in, N * 3 * sizeof(double)), "hipMalloc") &&
+        step(hipMalloc((void **)&d_out, N * sizeof(double)), "hipMalloc") &&
+        step(hipMemcpy(d_in, in, N * 3 * sizeof(double), hipMemcpyHostToDevice), "copy in") &&
+        step(bdpt_launch_clmath(op, d_in, d_out, n, ctx->stream), "launch") &&
+        step(hipStreamSynchronize(ctx->stream), "sync")) {
+        step(hipMemcpy(out, d_out, N * sizeof(double), hipMemcpyDeviceToHost), "copy out");
+    }
+    dev_free(d_in); dev_free(d_out);
+    return rc;
+}
+
+}  /* extern "C" */

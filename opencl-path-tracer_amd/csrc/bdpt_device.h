@@ -1,0 +1,229 @@
+/*
+ * bdpt_device.h -- per-lane device functions of the BDPT sample: generator,
+ * camera ray, light and cone sampling, the three primitive tests and the
+ * connection term.  Path state stays in registers; nothing here touches memory
+ * except the uniform-address scene reads.
+ *
+ * Each function states the reference lines whose result it must reproduce
+ * (kernel0.cl = /root/reference/src/kernel/kernel0.cl).  Arithmetic follows the
+ * numeric contract of include/bdpt_clmath.h; this translation unit is built
+ * with -ffp-contract=off.
+ */
+#ifndef BDPT_DEVICE_H
+#define BDPT_DEVICE_H
+
+#include "bdpt_layout.h"
+#include "../../include/bdpt.h"
+#include "../../include/bdpt_clmath.h"
+
+namespace bdpt {
+
+#define BDPT_DEV __device__ __forceinline__
+
+/* 48271^32 mod 2^32: the generator's stride between samples in STRIDED mode */
+constexpr uint32_t kSampleStride = 1820286465u;
+
+BDPT_DEV clm_f3 f3(const float *p) { return clm_make3(p[0], p[1], p[2]); }
+
+/* kernel0.cl:106-112.  (float)UINT_MAX is 2^32, and dividing by it is exact. */
+BDPT_DEV float rng_float(uint32_t &w, uint32_t &draws)
+{
+    w *= 48271u;
+    draws++;
+    return (float)w * 0x1p-32f;
+}
+
+BDPT_DEV uint32_t pow_u32(uint32_t base, uint32_t e)
+{
+    uint32_t r = 1u;
+    while (e) {
+        if (e & 1u) r *= base;
+        base *= base;
+        e >>= 1;
+    }
+    return r;
+}
+
+/* kernel0.cl:155-185 random_sample_cone */
+BDPT_DEV clm_f3 sample_cone(uint32_t &w, uint32_t &draws, clm_f3 axis, float half_angle)
+{
+    float p0 = rng_float(w, draws);
+    float p1 = rng_float(w, draws);
+    float p2 = rng_float(w, draws);
+    clm_f3 helper = clm_make3((float)((double)p2 * 2.0 - 1.0), 0.0f, 1.0f);          /* :163 */
+    clm_f3 t1 = clm_normalize3(clm_cross3(axis, helper));                            /* :168 */
+    clm_f3 t2 = clm_cross3(axis, t1);                                                /* :170 */
+    float sweep = p1 * 6.283185307f;                                                 /* :177 */
+    float lift = (float)((1.0 - ((double)(clm_acosf(p0) * 2.0f) * CLM_1_PI_F64)) * (double)half_angle);  /* :178 */
+    float sl, cl, ss, cs;
+    clm_sincos(lift, &sl, &cl);
+    clm_sincos(sweep, &ss, &cs);
+    clm_f3 ring = clm_mad3(ss, t2, clm_scale3(cs, t1));                              /* :182 */
+    return clm_mad3(sl, ring, clm_scale3(cl, axis));
+}
+
+/* kernel0.cl:547-569 sampleSphereSurface: point and outward normal on the light */
+BDPT_DEV void sample_light(uint32_t &w, uint32_t &draws, const bdpt_kargs &K, clm_f3 &pos, clm_f3 &nrm)
+{
+    float u0 = rng_float(w, draws);
+    float u1 = rng_float(w, draws);
+    float a0 = (float)((double)u0 * CLM_PI_F64);                                     /* :553 */
+    float theta = (float)clm_acos_f64(1.0 - (((double)2.0f * CLM_1_PI_F64) * (double)a0));   /* :554 */
+    float phi = (float)((double)(u1 * 2.0f) * CLM_PI_F64);                           /* :556 */
+    float st, ct, sp, cp;
+    clm_sincos(theta, &st, &ct);
+    clm_sincos(phi, &sp, &cp);
+    nrm = clm_make3(st * sp, ct, st * cp);                                           /* :558 */
+    pos = clm_mad3(K.light_r, nrm, f3(K.light_c));                                   /* :559 */
+}
+
+/* kernel0.cl:600-604: the pixel's normalised screen coordinate (fp64 at two sites) */
+BDPT_DEV void pixel_coord(const bdpt_kargs &K, int x, int y, float &xt, float &yt)
+{
+    float xf = clm_div((float)x, (float)K.width);
+    float yf = clm_div((float)y, (float)K.height);
+    xt = (float)(((double)xf * 2.0 - 1.0) * (double)K.aspect);
+    yt = (float)((double)yf * 2.0 - 1.0);
+}
+
+/* kernel0.cl:190-217: sub-pixel jitter (2 draws) and the camera ray */
+BDPT_DEV clm_f3 camera_ray(uint32_t &w, uint32_t &draws, const bdpt_kargs &K, float xt, float yt)
+{
+    float jx = rng_float(w, draws);
+    float jy = rng_float(w, draws);
+    float sx = xt + jx * K.delta_x;                                                  /* :198 */
+    float sy = yt + jy * K.delta_y;                                                  /* :199 */
+    clm_f3 look = f3(K.cam_look);
+    clm_f3 cy = clm_mad3(sy, f3(K.cam_up), look);                                    /* :211 */
+    clm_f3 cx = clm_mad3(sx, f3(K.cam_right), look);                                 /* :212 */
+    return clm_normalize3(clm_add3(cx, cy));                                         /* :215 */
+}
+
+/* closest-hit record; type < 0 is a miss */
+struct Hit {
+    int type, idx;
+    clm_f3 pos;
+    clm_f3 n;          /* shading normal, flipped to face the ray (kernel0.cl:461-473) */
+    uint32_t surf;
+};
+
+/* running best of the exhaustive search: strict '<' keeps the earliest
+ * (type, index) among equal distances (kernel0.cl:400, :424, :442) */
+struct Best {
+    float dist;
+    int type, idx;
+    clm_f3 pos;
+};
+
+/* kernel0.cl:314-361 + :396-406.  s = (c.xyz, r*r) */
+BDPT_DEV void test_sphere(Best &b, float4 s, int i, clm_f3 o, clm_f3 d)
+{
+    clm_f3 oc = clm_sub3(o, clm_make3(s.x, s.y, s.z));
+    float dot1 = clm_dot3(d, oc);                                                    /* :331 */
+    if (dot1 > 0) return;                                                            /* :333 */
+    float d2 = clm_dot3(oc, oc);                                                     /* :336 */
+    float disc = dot1 * dot1 - d2 + s.w;                                             /* :337 */
+    if (disc < 0) return;                                                            /* :341 */
+    float tA = -dot1 - clm_sqrt(disc);                                               /* :344-347 */
+    if (tA < 0) return;                                                              /* :350 */
+    clm_f3 p = clm_mad3(tA, d, o);                                                   /* :354 */
+    float dist = clm_distance3(p, o);                                                /* :398 */
+    if (dist < b.dist) { b.dist = dist; b.type = 0; b.idx = i; b.pos = p; }          /* :400 */
+}
+
+/* kernel0.cl:232-271 + :420-431.  q0 = (n.xyz,-), q1 = (pt.xyz,-) */
+BDPT_DEV void test_plane(Best &b, float4 q0, float4 q1, int i, clm_f3 o, clm_f3 d)
+{
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float angle = clm_dot3(d, n);                                                    /* :249 */
+    if (angle >= 0) return;                                                          /* :252 */
+    float temp = clm_dot3(clm_sub3(clm_make3(q1.x, q1.y, q1.z), o), n);              /* :256 */
+    float desc = clm_dot3(clm_scale3(temp, n), d);                                   /* :257 */
+    if (!(desc > 0)) return;                                                         /* :258 */
+    clm_f3 p = clm_mad3(clm_div(temp, angle), d, o);                                 /* :263-264 */
+    float dist = clm_distance3(p, o);                                                /* :422 */
+    if (dist < b.dist) { b.dist = dist; b.type = 1; b.idx = i; b.pos = p; }          /* :424 */
+}
+
+/* kernel0.cl:273-312 + :440-449 on the pre-laid-out record (bdpt_layout.h) */
+BDPT_DEV void test_triangle(Best &b, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, float e2z,
+                            int i, clm_f3 o, clm_f3 d)
+{
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float val = clm_dot3(d, n);                                                      /* :286 */
+    if (val > 0) return;                                                             /* :288 */
+    clm_f3 a = clm_make3(q0.w, q1.x, q1.y);
+    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
+    if (t < 0) return;                                                               /* :292 */
+    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
+    clm_f3 e0 = clm_make3(q1.z, q1.w, q2.x);
+    clm_f3 c = clm_make3(q2.y, q2.z, q2.w);
+    clm_f3 e1 = clm_make3(q3.x, q3.y, q3.z);
+    clm_f3 bb = clm_make3(q3.w, q4.x, q4.y);
+    clm_f3 e2 = clm_make3(q4.z, q4.w, e2z);
+    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), e0), n);                          /* :298 */
+    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
+    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
+    if (dA < 0 || dB < 0 || dC < 0) return;                                          /* :304 */
+    float dist = clm_distance3(p, o);                                                /* :441 */
+    if (dist < b.dist) { b.dist = dist; b.type = 2; b.idx = i; b.pos = p; }          /* :442 */
+}
+
+/* kernel0.cl:452-473: surface id, shading normal of the winner, flip toward the ray */
+BDPT_DEV Hit finish_hit(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
+{
+    Hit h;
+    h.type = b.type;
+    h.idx = b.idx;
+    h.pos = b.pos;
+    h.n = clm_make3(0.0f, 0.0f, 0.0f);
+    h.surf = 0;
+    if (b.type == 0) {
+        float4 s = S.sph[b.idx];
+        h.n = clm_normalize3(clm_sub3(clm_make3(s.x, s.y, s.z), b.pos));             /* :462 */
+        h.surf = S.sph_surf[b.idx];
+    } else if (b.type == 1) {
+        float4 q = S.pln[b.idx * BDPT_PLN_F4];
+        h.n = clm_make3(q.x, q.y, q.z);                                              /* :464 */
+        h.surf = S.pln_surf[b.idx];
+    } else if (b.type == 2) {
+        float4 q = S.tri[b.idx * BDPT_TRI_F4 + 5];
+        h.n = clm_make3(q.y, q.z, q.w);                                              /* :467 */
+        h.surf = S.tri_surf[b.idx];
+    }
+    if (clm_dot3(d, h.n) > 0) h.n = clm_neg3(h.n);                                   /* :471 */
+    return h;
+}
+
+/* id word chained into the hit hash: type<<28 | index, all ones on a miss */
+BDPT_DEV uint32_t hit_id(int type, int idx)
+{
+    return type < 0 ? 0xFFFFFFFFu : (((uint32_t)type << 28) | (uint32_t)idx);
+}
+
+/*
+ * kernel0.cl:712-744: contribution of one light-subpath vertex to the eye
+ * vertex, all four channels.  `vis` is the closest hit of the ray from the
+ * light vertex toward the eye vertex.
+ */
+BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, clm_f3 vert_pos, clm_f3 vert_n,
+                         clm_f3 test_dir, const float acc[4], float pre_factor, float out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (eye.type != vis.type || eye.idx != vis.idx) return;                          /* :712 */
+    if (!(clm_length3(clm_sub3(eye.pos, vis.pos)) < 0.0001f)) return;                /* :714 */
+    if (!(clm_dot3(eye.n, vis.n) > 0)) return;
+    clm_f3 pv = clm_sub3(vis.pos, vert_pos);                                         /* :716 */
+    float r2 = pv.x * pv.x + pv.y * pv.y + pv.z * pv.z;
+    float sf = (K.falloff == BDPT_FALLOFF_INV_SQ_PLUS_C) ? clm_div(1.0f, K.falloff_c + r2)
+                                                         : clm_div(1.0f, r2);        /* :719 */
+    float df = clm_dot3(eye.n, test_dir) * clm_dot3(vert_n, test_dir);               /* :732 */
+    df *= clm_sign(df);                                                              /* :733 */
+    float inv_imp = clm_div(1.0f, pre_factor);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = acc[k] * sf * df * inv_imp;                 /* :741 */
+}
+
+}  // namespace bdpt
+
+#endif

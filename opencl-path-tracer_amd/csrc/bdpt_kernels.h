@@ -1,0 +1,21 @@
+/*
+ * bdpt_kernels.h -- host-callable launchers of the kernels in bdpt_kernels.hip.
+ * Every launcher only enqueues on `stream`; none of them allocates or waits.
+ */
+#ifndef BDPT_KERNELS_H
+#define BDPT_KERNELS_H
+
+#include "bdpt_layout.h"
+
+/* spp samples for every pixel of the region in K; one lane per pixel. */
+hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
+/* Closest hit of n caller-supplied rays (6 floats each: origin, direction;
+ * origin[2*i], origin[2*i+1] = primitive to skip or (4,0)). Device pointers. */
+hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,
+                             float *out_pos, float *out_n, hipStream_t stream);
+
+/* Numeric-contract built-ins evaluated on the device (see the kernel). */
+hipError_t bdpt_launch_clmath(int op, const double *in, double *out, int n, hipStream_t stream);
+
+#endif

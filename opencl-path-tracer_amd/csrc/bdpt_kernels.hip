@@ -1,0 +1,280 @@
+/*
+ * bdpt_kernels.hip -- gfx950 kernels of the BDPT sample path.
+ *
+ * The unit of work is one path = one execution of the reference's
+ * bi_directional_path_trace (kernel0.cl:571-864) for one pixel.  A lane owns
+ * one pixel for the whole launch and runs `spp` consecutive samples of it with
+ * generator state, running accumulator and path state in registers; the
+ * accumulator is read and written once per launch (one float4 per pixel).
+ *
+ * Lane -> pixel: a wavefront covers an 8x8 pixel tile (lane & 7 = x, lane >> 3
+ * = y), a 256-thread workgroup four tiles side by side (32x8 pixels), so that
+ * the eye rays of a wavefront stay coherent and silhouette edges cut through as
+ * few wavefronts as possible.
+ *
+ * Built with -ffp-contract=off: the only fused operations are the ones the
+ * numeric contract (include/bdpt_clmath.h) writes out.
+ */
+#include "bdpt_device.h"
+#include "bdpt_kernels.h"
+
+namespace bdpt {
+
+/* ------------------------------------------------------------------------- */
+/* Direct variant: every lane walks the primitive arrays itself.  All lanes of
+ * a wavefront read the same record at the same time, so the reads are
+ * wave-uniform (scalar loads served by the constant cache).                    */
+/* ------------------------------------------------------------------------- */
+
+BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx)
+{
+    Best b;
+    b.dist = 10000.0f;                                                   /* kernel0.cl:374 */
+    b.type = -1;
+    b.idx = -1;
+    b.pos = clm_make3(0.0f, 0.0f, 0.0f);
+    const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
+    const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
+    const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
+    for (int i = 0; i < S.n_spheres; i++) {
+        float4 s = S.sph[i];
+        if (i != skip_s) test_sphere(b, s, i, o, d);
+    }
+    for (int i = 0; i < S.n_planes; i++) {
+        float4 q0 = S.pln[i * BDPT_PLN_F4 + 0], q1 = S.pln[i * BDPT_PLN_F4 + 1];
+        if (i != skip_p) test_plane(b, q0, q1, i, o, d);
+    }
+    for (int i = 0; i < S.n_triangles; i++) {
+        const float4 *q = S.tri + (size_t)i * BDPT_TRI_F4;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+        float e2z = q[5].x;
+        if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
+    }
+    return finish_hit(S, b, d);
+}
+
+/* One sample (kernel0.cl:592-847).  Returns true when the reference would have
+ * returned early (eye ray missed or hit a light, :645-656); col is then the raw
+ * value it writes. */
+template <bool AOV>
+BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
+                            uint32_t &hash, int eye_id[2], float col[4])
+{
+    const bdpt_dev_scene &S = K.scene;
+    rng_float(w, draws);                                                  /* :592, discarded */
+    clm_f3 dir = camera_ray(w, draws, K, xt, yt);
+    clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
+    Hit eye = closest_hit_direct(S, eye_pos, dir, 4, 0);                  /* :634 */
+    rays++;
+    if (AOV) { hash = (hash ^ hit_id(eye.type, eye.idx)) * 16777619u; eye_id[0] = eye.type; eye_id[1] = eye.idx; }
+
+    if (eye.type < 0) {                                                   /* :652-656 */
+        col[0] = col[1] = col[2] = col[3] = 0.0f;
+        return true;
+    }
+    const float4 eye_diffuse = S.surf[eye.surf * 2];
+    const float4 eye_emissive = S.surf[eye.surf * 2 + 1];
+    if (eye_emissive.w != 0.0f) {                                         /* :645-650 */
+        col[0] = eye_diffuse.x; col[1] = eye_diffuse.y; col[2] = eye_diffuse.z; col[3] = eye_diffuse.w;
+        return true;
+    }
+
+    clm_f3 vpos, vn;                                                      /* current light-subpath vertex */
+    sample_light(w, draws, K, vpos, vn);                                  /* :669 */
+    int vtype = K.light_origin_type, vidx = K.light_origin_index;
+
+    float full[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             /* :689 */
+    float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
+    float pre = K.pre_factor0;                                            /* :694 */
+    int taken = 0;
+    for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
+        clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));            /* :699 */
+        Hit vis = closest_hit_direct(S, vpos, tdir, vtype, vidx);         /* :705 */
+        rays++;
+        if (AOV) hash = (hash ^ hit_id(vis.type, vis.idx)) * 16777619u;
+        float contrib[4];
+        connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+        pre *= K.p_con;                                                   /* :745 */
+        if (!K.indirect_only || lti != 0) {                               /* :752-755 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) full[k] += contrib[k];
+        }
+        taken++;                                                          /* :757 */
+
+        clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                       /* :761 */
+        clm_f3 ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);         /* :767, :486 */
+        float fate = rng_float(w, draws);                                 /* :787 */
+        if (fate > K.p_con) break;                                        /* :788 */
+
+        Hit nxt = closest_hit_direct(S, lpos, ldir, vtype, vidx);         /* :793 */
+        rays++;
+        if (AOV) hash = (hash ^ hit_id(nxt.type, nxt.idx)) * 16777619u;
+        if (nxt.type < 0) break;                                          /* :812 */
+        const float4 nd = S.surf[nxt.surf * 2];
+        const float4 ne = S.surf[nxt.surf * 2 + 1];
+        if (ne.w != 0.0f) break;                                          /* :797-803 */
+        acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
+        vpos = nxt.pos; vn = nxt.n; vtype = nxt.type; vidx = nxt.idx;     /* :832 */
+    }
+
+    const float inv_taken = clm_div(1.0f, (float)taken);                  /* :846 */
+    const float ed[4] = {eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float c = K.light_emissive[k] * full[k] * inv_taken;
+        if (!K.indirect_only) c = c * ed[k];                              /* :844 / :846 */
+        col[k] = c;
+    }
+    return false;
+}
+
+template <bool AOV, bool COUNT>
+__global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
+    const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
+    if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
+    const size_t pix = (size_t)y * K.width + x;
+
+    float4 a4 = K.accum[pix];
+    float acc[4] = {a4.x, a4.y, a4.z, a4.w};
+    const uint32_t seed = K.seed_w[pix];
+    uint32_t w = seed;
+    uint32_t stride_state = 0;
+    if (K.rng_mode == BDPT_RNG_STRIDED) stride_state = seed * pow_u32(kSampleStride, K.first_sample);
+
+    uint32_t draws = 0, rays = 0, hash = 0;
+    if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
+    unsigned long long c_rays = 0, c_full = 0, c_early = 0;
+    int eye_id[2] = {-1, -1};
+    float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    float xt, yt;
+    pixel_coord(K, x, y, xt, yt);
+
+    for (int s = 0; s < K.spp; s++) {
+        const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
+        if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
+        const uint32_t w_before = w;
+        const uint32_t rays_before = rays;
+        const bool early = sample_direct<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+        if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
+
+        if (early && K.rng_mode == BDPT_RNG_STREAM) {
+            /* kernel0.cl:645-656: raw value written, history dropped, the seed is not
+             * written back -- so every later sample of this launch repeats this one
+             * exactly.  Account for the repeats and stop. */
+            w = w_before;
+            acc[0] = col[0]; acc[1] = col[1]; acc[2] = col[2]; acc[3] = col[3];
+            const int rest = K.spp - 1 - s;
+            if (AOV) {
+                const uint32_t id = hit_id(eye_id[0], eye_id[1]);
+                for (int r = 0; r < rest; r++) hash = (hash ^ id) * 16777619u;
+                draws += 3u * (uint32_t)rest;
+                rays += (uint32_t)rest;
+            }
+            if (COUNT) c_early += (unsigned long long)rest;
+            break;
+        }
+        if (K.accum_mode == BDPT_ACCUM_SUM) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = acc[k] + col[k];
+        } else if (n == 0) {                                              /* :855 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = col[k];
+        } else {                                                          /* :854 */
+            const float s1 = clm_div((float)n, (float)(n + 1));
+            const float s2 = clm_div(1.0f, (float)(n + 1));
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = clm_fma(col[k], s2, acc[k] * s1);
+        }
+    }
+
+    K.accum[pix] = make_float4(acc[0], acc[1], acc[2], acc[3]);           /* :863 */
+    if (K.rng_mode == BDPT_RNG_STREAM) K.seed_w[pix] = w;                 /* :861 */
+    if (AOV) {
+        K.aov_eye_hit[pix * 2] = eye_id[0];
+        K.aov_eye_hit[pix * 2 + 1] = eye_id[1];
+        K.aov_hit_hash[pix] = hash;
+        K.aov_radiance[pix] = make_float4(col[0], col[1], col[2], col[3]);
+        K.aov_rng_draws[pix] = draws;
+        K.aov_rays[pix] = rays;
+    }
+    if (COUNT) {
+        atomicAdd(&K.counters[0], c_rays);
+        atomicAdd(&K.counters[1], c_full);
+        atomicAdd(&K.counters[2], c_early);
+    }
+}
+
+/* Closest hit for caller-supplied rays: the unit the known-answer tests drive. */
+__global__ void bdpt_query_kernel(bdpt_dev_scene S, const float *rays, const int *origin, int n, int *out_id,
+                                  float *out_pos, float *out_n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    clm_f3 o = clm_make3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
+    clm_f3 d = clm_make3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    Hit h = closest_hit_direct(S, o, d, origin[i * 2], origin[i * 2 + 1]);
+    out_id[i * 2] = h.type;
+    out_id[i * 2 + 1] = h.idx;
+    out_pos[i * 3 + 0] = h.pos.x; out_pos[i * 3 + 1] = h.pos.y; out_pos[i * 3 + 2] = h.pos.z;
+    out_n[i * 3 + 0] = h.n.x; out_n[i * 3 + 1] = h.n.y; out_n[i * 3 + 2] = h.n.z;
+}
+
+/* Evaluates the numeric contract's built-ins on the device so that a test can
+ * compare them bit for bit with the host evaluation of the same header.
+ * op: 0 sin, 1 cos, 2 acosf, 3 acos_f64 (in/out as double), 4 sqrt, 5 a/b,
+ * 6 fma(a,b,c), 7 1/sqrt-normalised x of (a,b,c). */
+__global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = in[i * 3], b = in[i * 3 + 1], c = in[i * 3 + 2];
+    double r = 0.0;
+    float s, co;
+    switch (op) {
+    case 0: clm_sincos((float)a, &s, &co); r = s; break;
+    case 1: clm_sincos((float)a, &s, &co); r = co; break;
+    case 2: r = clm_acosf((float)a); break;
+    case 3: r = clm_acos_f64(a); break;
+    case 4: r = clm_sqrt((float)a); break;
+    case 5: r = clm_div((float)a, (float)b); break;
+    case 6: r = clm_fma((float)a, (float)b, (float)c); break;
+    case 7: r = clm_normalize3(clm_make3((float)a, (float)b, (float)c)).x; break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace bdpt
+
+/* ---- launch wrappers ------------------------------------------------------ */
+
+hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
+    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true>), grid, block, 0, stream, K);
+    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false>), grid, block, 0, stream, K);
+    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true>), grid, block, 0, stream, K);
+    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false>), grid, block, 0, stream, K);
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,
+                             float *out_pos, float *out_n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bdpt::bdpt_query_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, rays, origin, n, out_id,
+                       out_pos, out_n);
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_clmath(int op, const double *in, double *out, int n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bdpt::bdpt_clmath_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,80 @@
+/*
+ * bdpt_layout.h -- device-side data layout and the by-value kernel argument.
+ *
+ * The upload structs of include/bdpt.h (the reference's host AoS structs,
+ * src/include/geometry/primitives.h:6-64) are re-laid out once per upload into
+ * records of float4 that a wavefront reads with one uniform address per
+ * primitive.  Everything that does not depend on the ray is computed at upload
+ * with the same arithmetic the per-ray code of the reference uses, so hoisting
+ * it changes no bit of any result:
+ *
+ *   sphere   1 x float4 : (c.x, c.y, c.z, r*r)            kernel0.cl:331-337
+ *   plane    2 x float4 : (n.xyz, -), (pt.xyz, -)         kernel0.cl:249-264
+ *   triangle 6 x float4 :                                  kernel0.cl:285-300
+ *       q0 (n.x,  n.y,  n.z,  a.x)    n  = normalize(cross(b-a, c-a))
+ *       q1 (a.y,  a.z,  e0.x, e0.y)   e0 = c-a
+ *       q2 (e0.z, c.x,  c.y,  c.z)
+ *       q3 (e1.x, e1.y, e1.z, b.x)    e1 = b-c
+ *       q4 (b.y,  b.z,  e2.x, e2.y)   e2 = a-b
+ *       q5 (e2.z, ns.x, ns.y, ns.z)   ns = normalize(cross(a-b, b-c)), the
+ *                                     shading normal of kernel0.cl:467
+ *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
+ * Surface ids live in separate uint32 arrays (read once per query, for the
+ * winning primitive only).
+ */
+#ifndef BDPT_LAYOUT_H
+#define BDPT_LAYOUT_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define BDPT_TRI_F4 6
+#define BDPT_PLN_F4 2
+
+struct bdpt_dev_scene {
+    const float4 *sph;          /* [n_spheres] */
+    const uint32_t *sph_surf;   /* [n_spheres] */
+    const float4 *pln;          /* [n_planes * BDPT_PLN_F4] */
+    const uint32_t *pln_surf;   /* [n_planes] */
+    const float4 *tri;          /* [n_triangles * BDPT_TRI_F4] */
+    const uint32_t *tri_surf;   /* [n_triangles] */
+    const float4 *surf;         /* [n_surfaces * 2] */
+    int n_spheres, n_planes, n_triangles, n_surfaces;
+};
+
+struct bdpt_kargs {
+    bdpt_dev_scene scene;
+    /* per-pixel state, row-major y*width + x */
+    uint32_t *seed_w;           /* state.w of the reference's uint4 seed */
+    float4 *accum;
+    int32_t *aov_eye_hit;       /* 2 per pixel */
+    uint32_t *aov_hit_hash;
+    float4 *aov_radiance;
+    uint32_t *aov_rng_draws;
+    uint32_t *aov_rays;
+    unsigned long long *counters;   /* [3] rays, light-loop samples, eye-only samples */
+    int width, height;
+    int rx0, ry0, rw, rh;       /* region rendered by this launch */
+    int num_samples;            /* imgDesc.numSamples before the first sample */
+    int spp;
+    uint32_t first_sample;      /* STRIDED: sample_offset + num_samples */
+    /* camera (kernel0.cl:22-29) and what shoot_ray derives from it */
+    float cam_pos[3], cam_look[3], cam_up[3], cam_right[3];   /* right = cross(up, look) */
+    float aspect;               /* (float)W / (float)H, kernel0.cl:603 */
+    float delta_x, delta_y;     /* BLUR_FACTOR / W, / H, kernel0.cl:196-197 */
+    /* light (kernel0.cl:663-669) */
+    float light_c[3], light_r;
+    float light_emissive[4];
+    int light_origin_type, light_origin_index;
+    /* loop constants (kernel0.cl:683-694) */
+    int max_l;
+    float p_con;
+    float pre_factor0;
+    int indirect_only;
+    int rng_mode;
+    int falloff;
+    float falloff_c;
+    int accum_mode;
+};
+
+#endif

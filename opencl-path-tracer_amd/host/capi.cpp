@@ -1,0 +1,89 @@
+/*
+ * capi.cpp -- C-ABI over the host-side scene, camera and seed helpers, for
+ * bindings that cannot call C++ (the Python tests and the benchmark driver).
+ */
+#include "bdpt_host.h"
+
+using namespace bdpt_host;
+
+struct bdpt_host_scene {
+    Scene sc;
+};
+
+extern "C" {
+
+bdpt_host_scene *bdpt_host_scene_create(int kind, int n_soup, uint32_t seed)
+{
+    bdpt_host_scene *s = new bdpt_host_scene();
+    switch (kind) {
+    case 0: s->sc = cornell_scene(); break;
+    case 1: s->sc = cornell_planes_scene(); break;
+    case 2: s->sc = outdoor_scene(); break;
+    case 3: s->sc = soup_scene(n_soup, seed); break;
+    default: delete s; return nullptr;
+    }
+    return s;
+}
+
+void bdpt_host_scene_destroy(bdpt_host_scene *s) { delete s; }
+
+int bdpt_host_scene_counts(const bdpt_host_scene *s, int counts[4])
+{
+    if (!s || !counts) return -1;
+    counts[0] = (int)s->sc.spheres.size();
+    counts[1] = (int)s->sc.planes.size();
+    counts[2] = (int)s->sc.triangles.size();
+    counts[3] = (int)s->sc.surfaces.size();
+    return 0;
+}
+
+const bdpt_sphere *bdpt_host_scene_spheres(const bdpt_host_scene *s) { return s ? s->sc.spheres.data() : nullptr; }
+const bdpt_plane *bdpt_host_scene_planes(const bdpt_host_scene *s) { return s ? s->sc.planes.data() : nullptr; }
+const bdpt_triangle *bdpt_host_scene_triangles(const bdpt_host_scene *s) { return s ? s->sc.triangles.data() : nullptr; }
+const bdpt_surface *bdpt_host_scene_surfaces(const bdpt_host_scene *s) { return s ? s->sc.surfaces.data() : nullptr; }
+
+void bdpt_host_camera_reset(float radius, const float orientation[3], const float dir[3], bdpt_camera *out)
+{
+    ModelCamera cam;
+    cam.setRadius(radius);
+    cam.setOrientation({orientation[0], orientation[1], orientation[2]});
+    cam.reset({dir[0], dir[1], dir[2]});
+    *out = cam.getCLCamera();
+}
+
+void bdpt_host_scene_default_camera(const bdpt_host_scene *s, bdpt_camera *out)
+{
+    const float orientation[3] = {0.0f, -1.0f, 0.0f};                     /* main.cpp:518 */
+    const float dir[3] = {s->sc.view_dir.x, s->sc.view_dir.y, s->sc.view_dir.z};
+    bdpt_host_camera_reset(s->sc.view_radius, orientation, dir, out);
+}
+
+void bdpt_host_camera_orbit(float radius, const float orientation[3], const float dir[3], float speed_x, float speed_y,
+                            double dx, double dy, int steps, bdpt_camera *out, int *changed)
+{
+    ModelCamera cam;
+    cam.setSpeedX(speed_x);
+    cam.setSpeedY(speed_y);
+    cam.setRadius(radius);
+    cam.setOrientation({orientation[0], orientation[1], orientation[2]});
+    cam.reset({dir[0], dir[1], dir[2]});
+    out[0] = cam.getCLCamera();
+    cam.handleCursor(true, false, 0.0, 0.0);                              /* press: becomes active, no motion yet */
+    for (int i = 0; i < steps; i++) {
+        cam.handleCursor(true, false, dx, dy);
+        out[i + 1] = cam.getCLCamera();
+        if (changed) changed[i] = cam.isChanged();
+    }
+}
+
+void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t *out)
+{
+    make_seeds(width, height, global_seed, out);
+}
+
+int bdpt_host_write_pfm(const char *path, const float *rgba, int width, int height)
+{
+    return write_pfm(path, rgba, width, height) ? 0 : -1;
+}
+
+}  /* extern "C" */

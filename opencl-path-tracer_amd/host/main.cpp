@@ -1,0 +1,83 @@
+/*
+ * main.cpp -- headless counterpart of the reference's application
+ * (src/renderer/main.cpp:176-564): build the scene, create the context, upload,
+ * then run the frame loop for a fixed number of frames with a scripted camera
+ * instead of until the window closes, and write the image instead of
+ * presenting it.
+ *
+ *   bdpt_host [--scene cornell|planes|outdoor|soup] [--soup N] [--width W]
+ *             [--height H] [--frames F] [--spp S] [--orbit-frames K]
+ *             [--seed G] [--device D] [--out image.pfm] [--quiet]
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "bdpt_host.h"
+
+using namespace bdpt_host;
+
+int main(int argc, char **argv)
+{
+    std::string scene_name = "cornell", out_path;
+    int width = 1067, height = 600;                                       /* main.cpp:35-36 */
+    int frames = 64, spp = 1, orbit_frames = 0, n_soup = 100000, device = 0;
+    uint32_t seed = 0x5EEDu;
+    bool quiet = false;
+    for (int i = 1; i < argc; i++) {
+        auto next = [&](const char *flag) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "ERROR: %s needs a value\n", flag); std::exit(EXIT_FAILURE); }
+            return argv[++i];
+        };
+        if (!std::strcmp(argv[i], "--scene")) scene_name = next("--scene");
+        else if (!std::strcmp(argv[i], "--soup")) n_soup = std::atoi(next("--soup"));
+        else if (!std::strcmp(argv[i], "--width")) width = std::atoi(next("--width"));
+        else if (!std::strcmp(argv[i], "--height")) height = std::atoi(next("--height"));
+        else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(next("--frames"));
+        else if (!std::strcmp(argv[i], "--spp")) spp = std::atoi(next("--spp"));
+        else if (!std::strcmp(argv[i], "--orbit-frames")) orbit_frames = std::atoi(next("--orbit-frames"));
+        else if (!std::strcmp(argv[i], "--seed")) seed = (uint32_t)std::strtoul(next("--seed"), nullptr, 0);
+        else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next("--device"));
+        else if (!std::strcmp(argv[i], "--out")) out_path = next("--out");
+        else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else { std::fprintf(stderr, "ERROR: unknown argument %s\n", argv[i]); return EXIT_FAILURE; }
+    }
+
+    Scene scene;
+    if (scene_name == "cornell") scene = cornell_scene();
+    else if (scene_name == "planes") scene = cornell_planes_scene();
+    else if (scene_name == "outdoor") scene = outdoor_scene();
+    else if (scene_name == "soup") scene = soup_scene(n_soup);
+    else { std::fprintf(stderr, "ERROR: unknown scene %s\n", scene_name.c_str()); return EXIT_FAILURE; }
+
+    Renderer r(device, width, height);
+    r.verbose = !quiet;
+    r.setScene(scene);
+    r.setSeeds(seed);
+    std::printf("%s: %zu spheres, %zu planes, %zu triangles, %dx%d, %d frames x %d spp\n", bdpt_version(),
+                scene.spheres.size(), scene.planes.size(), scene.triangles.size(), width, height, frames, spp);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++) {
+        InputFrame in;
+        /* scripted mouse: hold the left button and drag for the first orbit_frames frames */
+        if (f < orbit_frames) { in.left_down = true; in.dx = 0.5 / 0.03; }
+        r.frame(in, spp);
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double paths = (double)width * height * (double)spp * frames;
+    std::printf("%d frames in %.3f s: %.2f Mpaths/s, %d samples accumulated\n", frames, sec, paths / sec / 1e6,
+                r.numSamples());
+
+    if (!out_path.empty()) {
+        std::vector<float> img = r.readImage();
+        if (!write_pfm(out_path, img.data(), width, height)) {
+            std::fprintf(stderr, "ERROR: cannot write %s\n", out_path.c_str());
+            return EXIT_FAILURE;
+        }
+        std::printf("wrote %s\n", out_path.c_str());
+    }
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,96 @@
+/*
+ * renderer.cpp -- the per-frame loop of the reference (mainLoop,
+ * src/renderer/main.cpp:100-172) and its one-time set-up (:513-546) over the
+ * C-ABI instead of OpenCL, without a window.
+ */
+#include <cstdio>
+#include <cstdlib>
+
+#include "bdpt_host.h"
+
+namespace bdpt_host {
+
+/* main.cpp:41-46 checkErr: print "ERROR: <what> (<code>)" and exit */
+void Renderer::check(int rc, const char *what)
+{
+    if (rc == BDPT_OK) return;
+    std::fprintf(stderr, "ERROR: %s (%d): %s\n", what, rc, bdpt_last_error(c));
+    std::exit(EXIT_FAILURE);
+}
+
+Renderer::Renderer(int device, int width, int height) : w(width), h(height)
+{
+    check(bdpt_create(device, width, height, &c), "bdpt_create");
+    cam.setSpeedX(0.03f);                                                 /* main.cpp:514 */
+    cam.setSpeedY(0.03f);                                                 /* :515 */
+    cam.setRadius(8.0f);                                                  /* :517 */
+    cam.setOrientation({0.0f, -1.0f, 0.0f});                              /* :518 */
+    cam.reset({1.0f, 0.1f, -0.1f});                                       /* :519 */
+}
+
+Renderer::~Renderer() { bdpt_destroy(c); }
+
+void Renderer::setScene(const Scene &scene)
+{
+    check(bdpt_upload_scene(c, scene.spheres.data(), (int)scene.spheres.size(), scene.planes.data(),
+                            (int)scene.planes.size(), scene.triangles.data(), (int)scene.triangles.size(),
+                            scene.surfaces.data(), (int)scene.surfaces.size()),
+          "bdpt_upload_scene");                                           /* main.cpp:534-539 */
+    cam.setRadius(scene.view_radius);
+    cam.reset(scene.view_dir);
+    bdpt_camera cl = cam.getCLCamera();
+    check(bdpt_set_camera(c, &cl), "bdpt_set_camera");                    /* main.cpp:524-533 */
+}
+
+void Renderer::setSeeds(uint32_t global_seed)
+{
+    std::vector<uint32_t> seeds((size_t)w * h * 4);
+    make_seeds(w, h, global_seed, seeds.data());
+    check(bdpt_upload_seeds(c, seeds.data()), "bdpt_upload_seeds");       /* main.cpp:538 */
+}
+
+void Renderer::setParams(const bdpt_params &p) { check(bdpt_set_params(c, &p), "bdpt_set_params"); }
+
+void Renderer::frame(const InputFrame &in, int spp)
+{
+    check(bdpt_render(c, spp), "bdpt_render");                            /* main.cpp:108-131 */
+    cam.handleCursor(in.left_down, in.middle_down, in.dx, in.dy);         /* :149 */
+    if (cam.isChanged()) {                                                /* :150-156 */
+        bdpt_camera cl = cam.getCLCamera();
+        check(bdpt_set_camera(c, &cl), "bdpt_set_camera");                /* zeroes the sample counter */
+    }
+    if (verbose && bdpt_num_samples(c) % 10 == 0)                         /* :168-169 */
+        std::printf("numSamples: %d\n", bdpt_num_samples(c));
+}
+
+int Renderer::numSamples() const { return bdpt_num_samples(c); }
+
+std::vector<float> Renderer::readImage()
+{
+    std::vector<float> img((size_t)w * h * 4);
+    check(bdpt_read_accum(c, img.data()), "bdpt_read_accum");
+    return img;
+}
+
+float Renderer::lastLaunchMs()
+{
+    float ms = 0.0f;
+    check(bdpt_last_launch_ms(c, &ms), "bdpt_last_launch_ms");
+    return ms;
+}
+
+bool write_pfm(const std::string &path, const float *rgba, int width, int height)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", width, height);
+    std::vector<float> row((size_t)width * 3);
+    for (int y = height - 1; y >= 0; y--) {
+        for (int x = 0; x < width; x++)
+            for (int k = 0; k < 3; k++) row[(size_t)x * 3 + k] = rgba[((size_t)y * width + x) * 4 + k];
+        if (std::fwrite(row.data(), sizeof(float), row.size(), f) != row.size()) { std::fclose(f); return false; }
+    }
+    return std::fclose(f) == 0;
+}
+
+}  // namespace bdpt_host

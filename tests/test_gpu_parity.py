@@ -1,0 +1,232 @@
+"""GPU parity: the HIP path through the C-ABI against the CPU oracle on the same
+seeded inputs.  Bars (stated once, used below):
+  - closest-hit primitive ids, hit-id hash chains, generator state and draw
+    counts: bit-exact;
+  - per-sample radiance and accumulated image: the arithmetic is specified
+    operation by operation (include/bdpt_clmath.h), so these are compared
+    bit-exact as well; RADIANCE_RTOL/ATOL is the documented fallback bar of the
+    north star (fp32 relative 1e-5, absolute 1e-7) and is asserted first so a
+    failure says how far off the values are.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_RTOL = 1e-5
+RADIANCE_ATOL = 1e-7
+
+
+def _pair(bdpt, oracle, scene, W, H, seed=0x5EED, **params):
+    seeds = bdpt.make_seeds(W, H, seed)
+    ctx = bdpt.Context(W, H)
+    p = bdpt.default_params(aov_enable=1, **params)
+    ctx.set_params(p)
+    ctx.upload_scene(scene)
+    ctx.upload_seeds(seeds)
+    ctx.set_camera(scene.camera)
+    st = oracle.State(W, H, seeds)
+    return ctx, st, p
+
+
+def _compare(bdpt, ctx, st, what=""):
+    eye = ctx.read_aov(bdpt.AOV_EYE_HIT)
+    assert np.array_equal(eye, st.eye_hit), what + " eye-hit ids differ at %d pixels" % np.count_nonzero((eye != st.eye_hit).any(-1))
+    hh = ctx.read_aov(bdpt.AOV_HIT_HASH)
+    assert np.array_equal(hh, st.hit_hash), what + " hit-id hash differs at %d pixels" % np.count_nonzero(hh != st.hit_hash)
+    assert np.array_equal(ctx.read_aov(bdpt.AOV_RNG_DRAWS), st.rng_draws), what + " draw counts differ"
+    assert np.array_equal(ctx.read_aov(bdpt.AOV_RAYS), st.rays), what + " ray counts differ"
+    assert np.array_equal(ctx.read_seeds(), st.seeds), what + " generator state differs"
+    rad = ctx.read_aov(bdpt.AOV_RADIANCE)
+    np.testing.assert_allclose(rad, st.radiance, rtol=RADIANCE_RTOL, atol=RADIANCE_ATOL, err_msg=what + " radiance")
+    acc = ctx.read_accum()
+    np.testing.assert_allclose(acc, st.accum, rtol=RADIANCE_RTOL, atol=RADIANCE_ATOL, err_msg=what + " accumulator")
+    assert np.array_equal(rad.view(np.uint32), st.radiance.view(np.uint32)), what + " radiance not bit-exact"
+    assert np.array_equal(acc.view(np.uint32), st.accum.view(np.uint32)), what + " accumulator not bit-exact"
+
+
+def test_clmath_device_matches_host_bitwise(bdpt, oracle):
+    """Every built-in of the numeric contract rounds identically on gfx950 and on the host."""
+    rng = np.random.default_rng(1)
+    n = 200000
+    ctx = bdpt.Context(8, 8)
+    x = rng.uniform(0.0, 2 * np.pi, n).astype(np.float32)
+    s = np.array([oracle.sincos(v) for v in x[:20000]], np.float32)
+    assert np.array_equal(ctx.clmath_eval(0, x[:20000]).astype(np.float32).view(np.uint32), s[:, 0].view(np.uint32))
+    assert np.array_equal(ctx.clmath_eval(1, x[:20000]).astype(np.float32).view(np.uint32), s[:, 1].view(np.uint32))
+    u = np.concatenate([rng.uniform(-1, 1, 20000), [0.0, 1.0, -1.0, 0.5, -0.5, 0.5000001, 1e-30]]).astype(np.float32)
+    a = np.array([oracle.acosf(v) for v in u], np.float32)
+    assert np.array_equal(ctx.clmath_eval(2, u).astype(np.float32).view(np.uint32), a.view(np.uint32))
+    ud = np.concatenate([rng.uniform(-1, 1, 20000), [0.0, 1.0, -1.0, 0.5, -0.5, 1 - 1e-10, -1 + 1e-10]])
+    ad = np.array([oracle.acos_f64(v) for v in ud], np.float64)
+    assert np.array_equal(ctx.clmath_eval(3, ud).view(np.uint64), ad.view(np.uint64))
+    # IEEE sqrt / div / fma against numpy (correctly rounded on the host)
+    v = np.abs(rng.standard_normal(n)).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
+    assert np.array_equal(ctx.clmath_eval(4, v).astype(np.float32).view(np.uint32), np.sqrt(v).view(np.uint32))
+    a32 = (rng.standard_normal(n) * 10.0 ** rng.integers(-15, 15, n)).astype(np.float32)
+    b32 = (rng.standard_normal(n) * 10.0 ** rng.integers(-15, 15, n)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        q = a32 / b32
+    got = ctx.clmath_eval(5, np.stack([a32, b32], 1)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), q.view(np.uint32))
+    c32 = rng.standard_normal(n).astype(np.float32)
+    a1 = rng.standard_normal(n).astype(np.float32)
+    b1 = rng.standard_normal(n).astype(np.float32)
+    fma = (a1.astype(np.float64) * b1.astype(np.float64) + c32.astype(np.float64)).astype(np.float32)  # exact product in f64, one rounding (double rounding is negligible but not impossible)
+    got = ctx.clmath_eval(6, np.stack([a1, b1, c32], 1)).astype(np.float32)
+    assert np.count_nonzero(got.view(np.uint32) != fma.view(np.uint32)) <= n // 100000 + 2
+    ctx.close()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_planes", "outdoor"])
+def test_closest_hit_ids_bit_exact_on_identical_rays(bdpt, oracle, scene_name):
+    scene = getattr(bdpt.Scene, scene_name)()
+    rng = np.random.default_rng(7)
+    n = 4000
+    o = rng.uniform(-2.9, 2.9, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    org = np.tile(np.array([4, 0], np.int32), (n, 1))
+    org[: n // 4] = [0, 0]          # rays leaving the light sphere skip it
+    org[n // 4: n // 2] = [2, 3]    # rays leaving triangle 3 skip it
+    ctx = bdpt.Context(8, 8)
+    ctx.upload_scene(scene)
+    ids, pos, nrm = ctx.query_rays(np.concatenate([o, d], 1), org)
+    for i in range(n):
+        hit, oid, opos, onrm = oracle.ray_intersect(scene, o[i], d[i], org[i])
+        assert tuple(ids[i]) == tuple(oid), "ray %d: gpu %s oracle %s" % (i, ids[i], oid)
+        if hit:
+            assert np.array_equal(pos[i].view(np.uint32), opos.view(np.uint32))
+            assert np.array_equal(nrm[i].view(np.uint32), onrm.view(np.uint32))
+    ctx.close()
+
+
+def test_cornell_per_sample_parity_stream_mode(bdpt, oracle):
+    """64x64 Cornell, 16 samples one launch each: ids, hashes, radiance, accumulator and seeds after every sample."""
+    scene = bdpt.Scene.cornell()
+    W = H = 64
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H)
+    for s in range(16):
+        ctx.render(1)
+        oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
+        _compare(bdpt, ctx, st, "sample %d:" % s)
+    assert ctx.num_samples == 16
+    ctx.close()
+
+
+def test_batched_launch_equals_sample_by_sample(bdpt, oracle):
+    """One launch of 24 samples gives the bits of 24 one-sample launches (the oracle runs them one by one)."""
+    scene = bdpt.Scene.cornell()
+    W, H = 96, 56
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=99)
+    ctx.render(24)
+    for _ in range(24):
+        oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
+    _compare(bdpt, ctx, st, "24 spp:")
+    ctx.render(5)
+    oracle.render(st, scene, scene.camera, p, 5, n_threads=8)
+    _compare(bdpt, ctx, st, "24+5 spp:")
+    ctx.close()
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("cornell_planes", 64, 48), ("outdoor", 80, 48)])
+def test_other_scenes_parity(bdpt, oracle, scene_name, W, H):
+    scene = getattr(bdpt.Scene, scene_name)()
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=3)
+    ctx.render(8)
+    oracle.render(st, scene, scene.camera, p, 8, n_threads=8)
+    _compare(bdpt, ctx, st, scene_name + ":")
+    ctx.close()
+
+
+def test_soup_scene_parity(bdpt, oracle):
+    """Cornell + 3000 soup triangles, 32x32 x 2 spp (the exhaustive search over many primitives)."""
+    scene = bdpt.Scene.soup(3000)
+    ctx, st, p = _pair(bdpt, oracle, scene, 32, 32, seed=5)
+    ctx.render(2)
+    oracle.render(st, scene, scene.camera, p, 2, n_threads=8)
+    _compare(bdpt, ctx, st, "soup:")
+    ctx.close()
+
+
+def test_strided_mode_and_sample_split(bdpt, oracle):
+    """STRIDED + SUM: two contexts rendering samples [0,6) and [6,12) add up to one context rendering [0,12)."""
+    scene = bdpt.Scene.cornell()
+    W, H = 64, 40
+    kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=11, **kw)
+    ctx.render(12)
+    oracle.render(st, scene, scene.camera, p, 12, n_threads=8)
+    _compare(bdpt, ctx, st, "strided 12:")
+    whole = ctx.read_accum()
+    ctx.close()
+
+    parts = []
+    for first in (0, 6):
+        c, s2, p2 = _pair(bdpt, oracle, scene, W, H, seed=11, **kw)
+        c.set_sample_offset(first)
+        c.render(6)
+        oracle.render(s2, scene, scene.camera, p2, 6, sample_offset=first, n_threads=8)
+        _compare(bdpt, c, s2, "strided part %d:" % first)
+        parts.append(c.read_accum())
+        c.close()
+    np.testing.assert_allclose(parts[0] + parts[1], whole, rtol=1e-5, atol=1e-6)
+
+
+def test_region_renders_only_its_pixels(bdpt, oracle):
+    scene = bdpt.Scene.cornell()
+    W, H = 64, 64
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=21)
+    region = (19, 7, 30, 41)   # deliberately not a multiple of the 8x8 wavefront tile
+    ctx.set_region(*region)
+    ctx.render(3)
+    oracle.render(st, scene, scene.camera, p, 3, region=region, n_threads=8)
+    _compare(bdpt, ctx, st, "region:")
+    acc = ctx.read_accum()
+    mask = np.ones((H, W), bool)
+    mask[7:48, 19:49] = False
+    assert not acc[mask].any()
+    ctx.close()
+
+
+def test_camera_move_resets_accumulation(bdpt, oracle):
+    scene = bdpt.Scene.cornell()
+    W, H = 48, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=31)
+    ctx.render(4)
+    oracle.render(st, scene, scene.camera, p, 4, n_threads=8)
+    cams, changed = bdpt.camera_orbit(8.0, (0, -1, 0), (1.0, 0.1, -0.1), 0.03, 0.03, 0.5 / 0.03, 0.0, 2)
+    assert changed.all()
+    ctx.set_camera(cams[2])
+    assert ctx.num_samples == 0
+    st.num_samples = 0
+    st.reset_aovs()
+    ctx.render(2)
+    oracle.render(st, scene, cams[2], p, 2, n_threads=8)
+    _compare(bdpt, ctx, st, "after move:")
+    ctx.close()
+
+
+def test_error_paths(bdpt):
+    ctx = bdpt.Context(16, 16)
+    with pytest.raises(bdpt.BdptError) as e:
+        ctx.render(1)
+    assert e.value.code == -3
+    with pytest.raises(bdpt.BdptError):
+        ctx.set_params(max_light_bounces=0)
+    with pytest.raises(bdpt.BdptError):
+        ctx.set_region(8, 8, 16, 16)
+    scene = bdpt.Scene.cornell()
+    bad = bdpt.Scene.cornell()
+    bad.triangles["surface"][3] = 99
+    with pytest.raises(bdpt.BdptError):
+        ctx.upload_scene(bad)
+    ctx.upload_scene(scene)
+    ctx.upload_seeds(bdpt.make_seeds(16, 16))
+    ctx.set_camera(scene.camera)
+    with pytest.raises(bdpt.BdptError):
+        ctx.render(0)
+    ctx.render(1)
+    ctx.close()
+    with pytest.raises(bdpt.BdptError):
+        bdpt.Context(16, 16, device=4096)

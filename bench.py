@@ -1,0 +1,175 @@
+"""BDPT throughput benchmark: Cornell box, 1920x1080, 1024 samples per pixel per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch: every rank renders the full
+frame for its own `spp` samples of every pixel (STRIDED generator mode, rank r
+owns sample indices [r*spp, (r+1)*spp)) into a sum accumulator, then the partial
+sums are combined on rank 0 by one RCCL reduce over xGMI.  Per-GPU work is fixed
+as N grows (weak scaling); value = all ranks' paths / max-over-ranks time.
+One path = one pixel-sample = one execution of the reference's
+bi_directional_path_trace (/root/reference/src/kernel/kernel0.cl:571-864).
+
+Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
+FP32 vector peak with the algorithmic flop count (rays counted by the device in
+a separate, untimed launch of the same workload); `cpu_baseline` times the CPU
+oracle on this host's cores on a bounded crop of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
+
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flops per primitive test / per ray
+F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per rank per step")
+    ap.add_argument("--kernel", type=int, default=0, help="bdpt_params.kernel_variant (0 auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch   # before the binding, so that both share one HIP runtime in this process
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the path tracer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+
+    import bdpt
+
+    W, H, SPP = args.width, args.height, args.spp
+    scene = bdpt.Scene.cornell()
+    ctx = bdpt.Context(W, H, device=local_rank)
+    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel))
+    ctx.upload_scene(scene)
+    ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED))
+    ctx.set_camera(scene.camera)
+    ctx.set_sample_offset(rank * SPP)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    ctx.bind_accum(accum.data_ptr())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    launch_ms = []
+
+    def step(record):
+        ctx.num_samples = 0                 # a fresh image each step; the first sample overwrites the accumulator
+        ctx.render_async(SPP)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if record:
+            launch_ms.append(ctx.last_launch_ms())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths_per_step = world * W * H * SPP
+    value = paths_per_step * args.steps / elapsed / 1e6
+    out = {
+        "metric": "BDPT Mpaths/s (whole node) at 1080p Cornell box",
+        "value": round(value, 2),
+        "unit": "Mpaths/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "Cornell box (3 spheres + 12 triangles), %dx%d, %d spp per GPU per step, exhaustive closest hit" % (W, H, SPP),
+            "rng_mode": "strided", "split": "samples per pixel" if world > 1 else "none",
+            "combine": "RCCL reduce(sum) of %dx%dx4 f32 to rank 0" % (W, H) if world > 1 else "none",
+        },
+    }
+
+    if rank == 0:
+        # algorithmic work of one launch: rays and path classes counted by device atomics, untimed
+        ctx.enable_counters(True)
+        ctx.num_samples = 0
+        ctx.render(SPP)
+        rays, full, early = ctx.read_counters()
+        ctx.enable_counters(False)
+        n_s, n_p, n_t = len(scene.spheres), len(scene.planes), len(scene.triangles)
+        f_ray = F_SPHERE * n_s + F_PLANE * n_p + F_TRIANGLE * n_t + F_RAY_FIXED
+        flops = rays * f_ray + full * F_PATH_FULL + early * F_PATH_EARLY
+        avg_s = sum(launch_ms) / len(launch_ms) / 1e3
+        achieved = flops / avg_s / 1e12
+        out["roofline"] = {
+            "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+            "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
+            "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
+        }
+        out["hbm_gbps_algorithmic"] = round(W * H * 36 / avg_s / 1e9, 3)   # 16 B read + 16 B write + 4 B seed per pixel per launch
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_bind as oracle   # the checker, timed here as the CPU baseline
+
+        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+        cw, ch, cspp = min(W, 640), min(H, 360), 64
+        region = ((W - cw) // 2, (H - ch) // 2, cw, ch)
+        st = oracle.State(W, H, bdpt.make_seeds(W, H, 0x5EED))
+        p = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+        t0 = time.perf_counter()
+        oracle.render(st, scene, scene.camera, p, cspp, region=region, n_threads=threads)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(cw * ch * cspp / cpu_s / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": "centre %dx%d crop of the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s" % (cw, ch, W, H, cspp, cpu_s),
+        }
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,8 @@ typedef struct bdpt_params {
     int32_t connection_falloff; /* kernel0.cl:719 is 1/r^2 (INV_SQ) */
     float falloff_c;            /* c of 1/(c + r^2) when INV_SQ_PLUS_C */
     /* MEAN: running mean prev*n/(n+1) + new/(n+1) (kernel0.cl:853-856).
-     * SUM: plain sum of samples, for combining partial images across GPUs. */
+     * SUM: plain sum of samples, for combining partial images across GPUs.
+     * In both modes the first sample after a reset (counter 0) overwrites. */
     int32_t accum_mode;
     int32_t aov_enable;         /* maintain the bdpt_read_aov() buffers */
     int32_t kernel_variant;     /* BDPT_KERNEL_*; AUTO picks by scene size */

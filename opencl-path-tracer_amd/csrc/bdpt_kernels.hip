@@ -177,12 +177,12 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
             if (COUNT) c_early += (unsigned long long)rest;
             break;
         }
-        if (K.accum_mode == BDPT_ACCUM_SUM) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = acc[k] + col[k];
-        } else if (n == 0) {                                              /* :855 */
+        if (n == 0) {                                                     /* :855 */
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = col[k];
+        } else if (K.accum_mode == BDPT_ACCUM_SUM) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = acc[k] + col[k];
         } else {                                                          /* :854 */
             const float s1 = clm_div((float)n, (float)(n + 1));
             const float s2 = clm_div(1.0f, (float)(n + 1));

@@ -471,10 +471,10 @@ static void render_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt
             for (int k = 0; k < 4; k++) acc[k] = S.col[k];
             continue;
         }
-        if (P->accum_mode == BDPT_ACCUM_SUM) {
-            for (int k = 0; k < 4; k++) acc[k] = acc[k] + S.col[k];
-        } else if (n == 0) {                                              /* :855 */
+        if (n == 0) {                                                     /* :855 */
             for (int k = 0; k < 4; k++) acc[k] = S.col[k];
+        } else if (P->accum_mode == BDPT_ACCUM_SUM) {
+            for (int k = 0; k < 4; k++) acc[k] = acc[k] + S.col[k];
         } else {                                                          /* :854 */
             float s1 = clm_div((float)n, (float)(n + 1));
             float s2 = clm_div(1.0f, (float)(n + 1));

@@ -172,7 +172,7 @@ void *bdpt_accum_device_ptr(bdpt_ctx *ctx);
  * cleared by bdpt_set_camera / bdpt_upload_scene / bdpt_upload_seeds. */
 enum {
     BDPT_AOV_EYE_HIT = 0,   /* int32[2] per pixel: (type, index) of the last sample's eye hit, (-1,-1) on a miss */
-    BDPT_AOV_HIT_HASH = 1,  /* uint32 per pixel: h = (h ^ id) * 16777619 over every closest-hit query, id = type<<28 | index, 0xFFFFFFFF on a miss */
+    BDPT_AOV_HIT_HASH = 1,  /* uint32 per pixel: h = (h ^ id) * 16777619 + 0x9E3779B9 over every closest-hit query, id = type<<28 | index, 0xFFFFFFFF on a miss */
     BDPT_AOV_RADIANCE = 2,  /* float[4] per pixel: the last sample's value before accumulation */
     BDPT_AOV_RNG_DRAWS = 3, /* uint32 per pixel: generator draws since reset */
     BDPT_AOV_RAYS = 4       /* uint32 per pixel: closest-hit queries since reset */

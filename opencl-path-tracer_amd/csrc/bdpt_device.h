@@ -224,6 +224,10 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
     for (int k = 0; k < 4; k++) out[k] = acc[k] * sf * df * inv_imp;                 /* :741 */
 }
 
+/* one link of the per-pixel hit-id chain (the additive constant keeps a run of
+ * zero ids from pinning the chain at zero) */
+BDPT_DEV uint32_t hash_step(uint32_t h, uint32_t id) { return (h ^ id) * 16777619u + 0x9E3779B9u; }
+
 }  // namespace bdpt
 
 #endif

@@ -66,7 +66,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
     Hit eye = closest_hit_direct(S, eye_pos, dir, 4, 0);                  /* :634 */
     rays++;
-    if (AOV) { hash = (hash ^ hit_id(eye.type, eye.idx)) * 16777619u; eye_id[0] = eye.type; eye_id[1] = eye.idx; }
+    if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
 
     if (eye.type < 0) {                                                   /* :652-656 */
         col[0] = col[1] = col[2] = col[3] = 0.0f;
@@ -91,7 +91,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));            /* :699 */
         Hit vis = closest_hit_direct(S, vpos, tdir, vtype, vidx);         /* :705 */
         rays++;
-        if (AOV) hash = (hash ^ hit_id(vis.type, vis.idx)) * 16777619u;
+        if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
         float contrib[4];
         connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
         pre *= K.p_con;                                                   /* :745 */
@@ -108,7 +108,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
 
         Hit nxt = closest_hit_direct(S, lpos, ldir, vtype, vidx);         /* :793 */
         rays++;
-        if (AOV) hash = (hash ^ hit_id(nxt.type, nxt.idx)) * 16777619u;
+        if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
         if (nxt.type < 0) break;                                          /* :812 */
         const float4 nd = S.surf[nxt.surf * 2];
         const float4 ne = S.surf[nxt.surf * 2 + 1];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
             const int rest = K.spp - 1 - s;
             if (AOV) {
                 const uint32_t id = hit_id(eye_id[0], eye_id[1]);
-                for (int r = 0; r < rest; r++) hash = (hash ^ id) * 16777619u;
+                for (int r = 0; r < rest; r++) hash = hash_step(hash, id);
                 draws += 3u * (uint32_t)rest;
                 rays += (uint32_t)rest;
             }

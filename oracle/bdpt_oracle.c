@@ -282,7 +282,7 @@ static Full ray_intersect(Lane *L, const Scene *sc, clm_f3 vPos, clm_f3 vDir,
     /* bookkeeping for the parity outputs (not in the reference) */
     L->rays++;
     uint32_t id = primType < 0 ? 0xFFFFFFFFu : (((uint32_t)primType << 28) | (uint32_t)index);
-    L->hash = (L->hash ^ id) * 16777619u;
+    L->hash = (L->hash ^ id) * 16777619u + 0x9E3779B9u;
     return full;
 }
 

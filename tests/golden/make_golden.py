@@ -1,0 +1,94 @@
+"""Regenerates the golden fixtures in this directory with the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+PARITY UNPINNED: the reference ships no fixtures and cannot be executed in this
+environment, so these vectors are outputs of the oracle (oracle/bdpt_oracle.c),
+not of the reference.  They pin the oracle against regressions and let the GPU
+path be checked without the oracle present.  Each .npz holds the inputs (scene
+arrays, camera, seeds, parameter fields) and the expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import bdpt  # noqa: E402  (host-side scene/camera/seed helpers only; no GPU call is made)
+import oracle_bind as oracle  # noqa: E402
+
+PARAM_FIELDS = [f for f, _ in bdpt.Params._fields_]
+
+
+def params_dict(p):
+    return {"param_" + f: np.asarray(getattr(p, f)) for f in PARAM_FIELDS}
+
+
+def render_case(name, scene, W, H, spp, seed, sample_offset=0, camera=None, **pkw):
+    cam = scene.camera if camera is None else camera
+    seeds = bdpt.make_seeds(W, H, seed)
+    p = bdpt.default_params(aov_enable=1, **pkw)
+    st = oracle.State(W, H, seeds)
+    per = {k: [] for k in ("eye_hit", "hit_hash", "radiance", "accum", "rng_draws", "rays")}
+    for _ in range(spp):
+        oracle.render(st, scene, cam, p, 1, sample_offset=sample_offset, n_threads=4)
+        per["eye_hit"].append(st.eye_hit.copy())
+        per["hit_hash"].append(st.hit_hash.copy())
+        per["radiance"].append(st.radiance.copy())
+        per["accum"].append(st.accum.copy())
+        per["rng_draws"].append(st.rng_draws.copy())
+        per["rays"].append(st.rays.copy())
+    out = dict(width=np.asarray(W), height=np.asarray(H), spp=np.asarray(spp), sample_offset=np.asarray(sample_offset),
+               spheres=scene.spheres, planes=scene.planes, triangles=scene.triangles, surfaces=scene.surfaces,
+               camera=np.asarray(cam), seeds=seeds, seeds_after=st.seeds, **params_dict(p))
+    for k, v in per.items():
+        out["out_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    return st, per
+
+
+def main():
+    # generator known answers
+    seeds = np.array([1, 12345, 0x7FFFFFFF], np.uint32)
+    fl, wd = zip(*[oracle.rng_sequence(int(s), 32) for s in seeds])
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), seeds=seeds, floats=np.stack(fl), words=np.stack(wd))
+
+    cornell = bdpt.Scene.cornell()
+    st, per = render_case("cornell_64x36_4spp", cornell, 64, 36, 4, 0x5EED)
+    eye = per["eye_hit"][-1]
+    assert ((eye[..., 0] == 0) & (eye[..., 1] == 0)).any(), "fixture must contain a pixel that sees the light directly"
+    assert (eye[..., 0] == -1).any(), "fixture must contain a pixel whose eye ray misses"
+    render_case("cornell_strided_sum_32x32_3spp_from5", cornell, 32, 32, 3, 77, sample_offset=5,
+                rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    render_case("cornell_variants_24x24_3spp", cornell, 24, 24, 3, 5, light_origin=bdpt.LIGHT_ORIGIN_NONE,
+                connection_falloff=bdpt.FALLOFF_INV_SQ_PLUS_C, falloff_c=0.5, indirect_only=1, max_light_bounces=3,
+                p_continue=0.6, blur_factor=1.0)
+    render_case("planes_24x24_3spp", bdpt.Scene.cornell_planes(), 24, 24, 3, 9)
+    render_case("outdoor_32x24_3spp", bdpt.Scene.outdoor(), 32, 24, 3, 13)
+    render_case("soup500_16x16_2spp", bdpt.Scene.soup(500), 16, 16, 2, 21)
+    cams, _ = bdpt.camera_orbit(8.0, (0, -1, 0), (1.0, 0.1, -0.1), 0.03, 0.03, 0.5 / 0.03, 0.25 / 0.03, 7)
+    render_case("cornell_moved_camera_24x24_2spp", cornell, 24, 24, 2, 3, camera=cams[7])
+
+    # closest-hit regression vectors on the triangle box
+    rng = np.random.default_rng(123)
+    n = 256
+    o = rng.uniform(-2.9, 2.9, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    org = np.tile(np.array([4, 0], np.int32), (n, 1))
+    org[:64] = [2, 5]
+    ids, pos, nrm = [], [], []
+    for i in range(n):
+        _, a, b, c = oracle.ray_intersect(cornell, o[i], d[i], org[i])
+        ids.append(a.copy()); pos.append(b.copy()); nrm.append(c.copy())
+    np.savez_compressed(os.path.join(HERE, "closest_hit_cornell.npz"), origins=o, dirs=d, origin_ids=org,
+                        ids=np.stack(ids), pos=np.stack(pos), normals=np.stack(nrm))
+    print("fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+"""Loads a golden fixture (tests/golden/*.npz) back into scene / params / expected outputs."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+RENDER_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*spp*.npz")))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def unpack(bdpt, g):
+    scene = bdpt.Scene(g["spheres"], g["planes"], g["triangles"], g["surfaces"], g["camera"])
+    p = bdpt.default_params()
+    for f, _ in bdpt.Params._fields_:
+        setattr(p, f, g["param_" + f].item())
+    return scene, p, int(g["width"]), int(g["height"]), int(g["spp"]), int(g["sample_offset"])

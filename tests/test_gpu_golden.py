@@ -1,0 +1,41 @@
+"""GPU path against the committed golden fixtures (no oracle involved at run time)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", gu.RENDER_CASES)
+def test_render_matches_golden(bdpt, case):
+    g = gu.load(case)
+    scene, p, W, H, spp, off = gu.unpack(bdpt, g)
+    with bdpt.Context(W, H) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(g["seeds"])
+        ctx.set_camera(scene.camera)
+        ctx.set_sample_offset(off)
+        for s in range(spp):
+            ctx.render(1)
+            assert np.array_equal(ctx.read_aov(bdpt.AOV_EYE_HIT), g["out_eye_hit"][s])
+            assert np.array_equal(ctx.read_aov(bdpt.AOV_HIT_HASH), g["out_hit_hash"][s])
+            assert np.array_equal(ctx.read_aov(bdpt.AOV_RNG_DRAWS), g["out_rng_draws"][s])
+            assert np.array_equal(ctx.read_aov(bdpt.AOV_RAYS), g["out_rays"][s])
+            rad = ctx.read_aov(bdpt.AOV_RADIANCE)
+            np.testing.assert_allclose(rad, g["out_radiance"][s], rtol=1e-5, atol=1e-7)
+            assert np.array_equal(rad.view(np.uint32), g["out_radiance"][s].view(np.uint32))
+            assert np.array_equal(ctx.read_accum().view(np.uint32), g["out_accum"][s].view(np.uint32))
+        assert np.array_equal(ctx.read_seeds(), g["seeds_after"])
+
+
+def test_closest_hit_matches_golden(bdpt):
+    g = gu.load("closest_hit_cornell")
+    with bdpt.Context(8, 8) as ctx:
+        ctx.upload_scene(bdpt.Scene.cornell())
+        ids, pos, nrm = ctx.query_rays(np.concatenate([g["origins"], g["dirs"]], 1), g["origin_ids"])
+    assert np.array_equal(ids, g["ids"])
+    hit = ids[:, 0] >= 0
+    assert np.array_equal(pos[hit].view(np.uint32), g["pos"][hit].view(np.uint32))
+    assert np.array_equal(nrm[hit].view(np.uint32), g["normals"][hit].view(np.uint32))

@@ -99,6 +99,21 @@ BDPT_DEV clm_f3 camera_ray(uint32_t &w, uint32_t &draws, const bdpt_kargs &K, fl
     return clm_normalize3(clm_add3(cx, cy));                                         /* :215 */
 }
 
+/*
+ * Scene records are read with a wave-uniform address.  Reading them through the
+ * constant address space tells the compiler the bytes never change during the
+ * launch, so it always uses scalar loads (s_load_dwordx4/x8/x16 through the
+ * constant cache, results in SGPRs that the VALU consumes directly) whatever
+ * other code surrounds the load.
+ */
+typedef float bdpt_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) bdpt_v4f *const_v4f_ptr;
+BDPT_DEV float4 uload(const float4 *base, size_t i)
+{
+    const bdpt_v4f v = ((const_v4f_ptr)(uintptr_t)base)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 /* closest-hit record; type < 0 is a miss */
 struct Hit {
     int type, idx;
@@ -107,13 +122,53 @@ struct Hit {
     uint32_t surf;
 };
 
-/* running best of the exhaustive search: strict '<' keeps the earliest
- * (type, index) among equal distances (kernel0.cl:400, :424, :442) */
+/*
+ * Running best of the exhaustive search.  The reference keeps the hit whose
+ * distance sqrt(d2) is strictly smaller than the best so far, starting from
+ * 10000 (kernel0.cl:374, :398-400, :422-424, :441-442), so ties go to the
+ * earliest (type, index).  sqrt is monotone, so the same decisions can be made
+ * on squared distances and the square root is only needed when two squared
+ * distances are so close that their roots might round to the same float:
+ *   d2 >= best.d2             -> sqrt(d2) >= sqrt(best.d2): rejected, exactly as the reference
+ *   d2 <  best.d2 * (1-1e-6)  -> the roots differ by > 3 ulp: accepted without a root
+ *   in between (rare)         -> both roots are taken and compared, as the reference does.
+ * best.d2 starts at 1e8 = 10000^2, whose root is exactly the reference's 10000.
+ */
 struct Best {
-    float dist;
+    float d2, d2_lo;
     int type, idx;
     clm_f3 pos;
 };
+
+BDPT_DEV void best_init(Best &b)
+{
+    b.d2 = 1.0e8f;
+    b.d2_lo = 9.99999e7f;
+    b.type = -1;
+    b.idx = -1;
+    b.pos = clm_make3(0.0f, 0.0f, 0.0f);
+}
+
+BDPT_DEV void best_consider(Best &b, clm_f3 p, clm_f3 o, int type, int i)
+{
+    const clm_f3 v = clm_sub3(p, o);
+    const float d2 = clm_dot3(v, v);                       /* distance(p, o)^2 before the root */
+    bool take = d2 < b.d2_lo;
+    const bool close_call = !take && d2 < b.d2;
+    /* a wave-uniform branch on the vote keeps the two roots out of the common path
+     * (a plain 'if' is flattened into straight-line code by the compiler) */
+    if (__builtin_amdgcn_ballot_w64(close_call) != 0) {
+        asm volatile("");                /* not speculatable: keeps this block a real branch */
+        if (close_call) take = clm_sqrt(d2) < clm_sqrt(b.d2);
+    }
+    if (take) {
+        b.d2 = d2;
+        b.d2_lo = d2 > 1.0e-30f ? d2 * 0.999999f : 0.0f;  /* below that every later candidate takes the exact branch */
+        b.type = type;
+        b.idx = i;
+        b.pos = p;
+    }
+}
 
 /* kernel0.cl:314-361 + :396-406.  s = (c.xyz, r*r) */
 BDPT_DEV void test_sphere(Best &b, float4 s, int i, clm_f3 o, clm_f3 d)
@@ -127,8 +182,7 @@ BDPT_DEV void test_sphere(Best &b, float4 s, int i, clm_f3 o, clm_f3 d)
     float tA = -dot1 - clm_sqrt(disc);                                               /* :344-347 */
     if (tA < 0) return;                                                              /* :350 */
     clm_f3 p = clm_mad3(tA, d, o);                                                   /* :354 */
-    float dist = clm_distance3(p, o);                                                /* :398 */
-    if (dist < b.dist) { b.dist = dist; b.type = 0; b.idx = i; b.pos = p; }          /* :400 */
+    best_consider(b, p, o, 0, i);                                                    /* :398-406 */
 }
 
 /* kernel0.cl:232-271 + :420-431.  q0 = (n.xyz,-), q1 = (pt.xyz,-) */
@@ -141,8 +195,7 @@ BDPT_DEV void test_plane(Best &b, float4 q0, float4 q1, int i, clm_f3 o, clm_f3 
     float desc = clm_dot3(clm_scale3(temp, n), d);                                   /* :257 */
     if (!(desc > 0)) return;                                                         /* :258 */
     clm_f3 p = clm_mad3(clm_div(temp, angle), d, o);                                 /* :263-264 */
-    float dist = clm_distance3(p, o);                                                /* :422 */
-    if (dist < b.dist) { b.dist = dist; b.type = 1; b.idx = i; b.pos = p; }          /* :424 */
+    best_consider(b, p, o, 1, i);                                                    /* :422-430 */
 }
 
 /* kernel0.cl:273-312 + :440-449 on the pre-laid-out record (bdpt_layout.h) */
@@ -165,8 +218,7 @@ BDPT_DEV void test_triangle(Best &b, float4 q0, float4 q1, float4 q2, float4 q3,
     float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
     float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
     if (dA < 0 || dB < 0 || dC < 0) return;                                          /* :304 */
-    float dist = clm_distance3(p, o);                                                /* :441 */
-    if (dist < b.dist) { b.dist = dist; b.type = 2; b.idx = i; b.pos = p; }          /* :442 */
+    best_consider(b, p, o, 2, i);                                                    /* :441-448 */
 }
 
 /* kernel0.cl:452-473: surface id, shading normal of the winner, flip toward the ray */

@@ -29,25 +29,23 @@ namespace bdpt {
 BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx)
 {
     Best b;
-    b.dist = 10000.0f;                                                   /* kernel0.cl:374 */
-    b.type = -1;
-    b.idx = -1;
-    b.pos = clm_make3(0.0f, 0.0f, 0.0f);
+    best_init(b);                                                         /* kernel0.cl:374, :384-385 */
     const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
     const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
     const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
     for (int i = 0; i < S.n_spheres; i++) {
-        float4 s = S.sph[i];
+        float4 s = uload(S.sph, i);
         if (i != skip_s) test_sphere(b, s, i, o, d);
     }
     for (int i = 0; i < S.n_planes; i++) {
-        float4 q0 = S.pln[i * BDPT_PLN_F4 + 0], q1 = S.pln[i * BDPT_PLN_F4 + 1];
+        float4 q0 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 0), q1 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 1);
         if (i != skip_p) test_plane(b, q0, q1, i, o, d);
     }
     for (int i = 0; i < S.n_triangles; i++) {
-        const float4 *q = S.tri + (size_t)i * BDPT_TRI_F4;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-        float e2z = q[5].x;
+        const size_t r = (size_t)i * BDPT_TRI_F4;
+        float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2), q3 = uload(S.tri, r + 3),
+               q4 = uload(S.tri, r + 4);
+        float e2z = uload(S.tri, r + 5).x;
         if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
     }
     return finish_hit(S, b, d);
@@ -129,7 +127,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
 }
 
 template <bool AOV, bool COUNT>
-__global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
+__global__ __launch_bounds__(256, 5) void bdpt_direct_kernel(const bdpt_kargs K)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);

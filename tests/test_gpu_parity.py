@@ -101,6 +101,43 @@ def test_closest_hit_ids_bit_exact_on_identical_rays(bdpt, oracle, scene_name):
     ctx.close()
 
 
+def test_near_ties_resolve_like_the_reference_order(bdpt, oracle):
+    """Rays aimed at the diagonals and edges shared by two wall triangles: both triangles report a hit at (almost)
+    the same distance, and the winner must be the one the sequential strict-'<' search keeps."""
+    scene = bdpt.Scene.cornell()
+    rng = np.random.default_rng(11)
+    tri = scene.triangles
+    targets = []
+    for k in range(0, 12, 2):                       # the two triangles of wall k//2 share the edge p1-p2 of the first
+        a, b = tri["p1"][k, :3], tri["p2"][k, :3]
+        for t in rng.uniform(0.02, 0.98, 60):
+            targets.append(a + np.float32(t) * (b - a))
+    for _ in range(120):                            # box edges shared by two walls
+        c = rng.choice([-3.0, 3.0], 3)
+        c[rng.integers(0, 3)] = rng.uniform(-2.9, 2.9)
+        targets.append(c.astype(np.float32))
+    targets = np.array(targets, np.float32)
+    o = rng.uniform(-1.0, 1.0, targets.shape).astype(np.float32)
+    o[::7] = 0.0                                    # exact ties from the centre
+    d = targets - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    org = np.tile(np.array([4, 0], np.int32), (len(d), 1))
+    ctx = bdpt.Context(8, 8)
+    ctx.upload_scene(scene)
+    ids, pos, nrm = ctx.query_rays(np.concatenate([o, d], 1), org)
+    exact_ties = 0
+    for i in range(len(d)):
+        hit, oid, opos, onrm = oracle.ray_intersect(scene, o[i], d[i], org[i])
+        assert tuple(ids[i]) == tuple(oid), "ray %d: gpu %s oracle %s" % (i, ids[i], oid)
+        assert np.array_equal(pos[i].view(np.uint32), opos.view(np.uint32))
+        if oid[0] == 2:
+            other = oid[1] ^ 1
+            h2, p2 = oracle.ray_primitive("triangle", tri[other:other + 1], o[i], d[i])
+            exact_ties += int(h2 and np.linalg.norm(p2 - o[i]) == np.linalg.norm(opos - o[i]))
+    assert exact_ties > 10
+    ctx.close()
+
+
 def test_cornell_per_sample_parity_stream_mode(bdpt, oracle):
     """64x64 Cornell, 16 samples one launch each: ids, hashes, radiance, accumulator and seeds after every sample."""
     scene = bdpt.Scene.cornell()

@@ -8,7 +8,7 @@ PKG     := opencl-path-tracer_amd
 CSRC    := $(PKG)/csrc
 ARCH    ?= gfx950
 
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wno-unused-function
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
 ORCFLAGS := -O2 -std=c11 -ffp-contract=off -fPIC -shared -fopenmp -Wall -Wno-unused-function
 
 LIB      := $(PKG)/libbdpt_amd.so

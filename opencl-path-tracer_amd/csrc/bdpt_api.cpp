@@ -253,8 +253,9 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-    std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4), tri((size_t)n_triangles * BDPT_TRI_F4),
-        surf((size_t)n_surfaces * 2);
+    /* the triangle array carries one zeroed record past the end: the search prefetches record i+1 */
+    std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4),
+        tri(((size_t)n_triangles + 1) * BDPT_TRI_F4, make_float4(0.f, 0.f, 0.f, 0.f)), surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];

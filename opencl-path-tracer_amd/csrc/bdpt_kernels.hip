@@ -46,6 +46,9 @@ BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int
         float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2), q3 = uload(S.tri, r + 3),
                q4 = uload(S.tri, r + 4);
         float e2z = uload(S.tri, r + 5).x;
+        /* pin the whole record here: otherwise the compiler sinks the second half of the load
+         * into the edge tests and every triangle pays two scalar-load round trips instead of one */
+        asm volatile("" ::"s"(q4.x), "s"(e2z));
         if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
     }
     return finish_hit(S, b, d);

@@ -75,7 +75,10 @@ enum { BDPT_RNG_STREAM = 0, BDPT_RNG_STRIDED = 1 };
 enum { BDPT_LIGHT_ORIGIN_SELF = 0, BDPT_LIGHT_ORIGIN_NONE = 1 };
 enum { BDPT_FALLOFF_INV_SQ = 0, BDPT_FALLOFF_INV_SQ_PLUS_C = 1 };
 enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
-enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_WAVEFRONT = 2 };
+/* DIRECT: every ray walks the primitives on its own. DUAL: the connection ray and the
+ * bounce ray of a light-subpath vertex walk them together, packed two to a register
+ * pair. AUTO = DUAL. Results are identical. */
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2 };
 
 typedef struct bdpt_params {
     int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */
@@ -99,7 +102,7 @@ typedef struct bdpt_params {
      * In both modes the first sample after a reset (counter 0) overwrites. */
     int32_t accum_mode;
     int32_t aov_enable;         /* maintain the bdpt_read_aov() buffers */
-    int32_t kernel_variant;     /* BDPT_KERNEL_*; AUTO picks by scene size */
+    int32_t kernel_variant;     /* BDPT_KERNEL_* */
 } bdpt_params;
 
 typedef struct bdpt_ctx bdpt_ctx;

@@ -10,6 +10,9 @@
 /* spp samples for every pixel of the region in K; one lane per pixel. */
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
+/* The same work with the connection and bounce rays of a vertex traced together (packed FP32 math). */
+hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
 /* Closest hit of n caller-supplied rays (6 floats each: origin, direction;
  * origin[2*i], origin[2*i+1] = primitive to skip or (4,0)). Device pointers. */
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

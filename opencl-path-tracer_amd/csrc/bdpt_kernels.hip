@@ -16,6 +16,7 @@
  * numeric contract (include/bdpt_clmath.h) writes out.
  */
 #include "bdpt_device.h"
+#include "bdpt_device2.h"
 #include "bdpt_kernels.h"
 
 namespace bdpt {
@@ -129,8 +130,12 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     return false;
 }
 
-template <bool AOV, bool COUNT>
-__global__ __launch_bounds__(256, 5) void bdpt_direct_kernel(const bdpt_kargs K)
+template <bool AOV>
+BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
+                          uint32_t &hash, int eye_id[2], float col[4]);   /* defined below */
+
+template <bool AOV, bool COUNT, bool DUAL>
+__global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(256, 5) void bdpt_direct_kernel(const bdpt_kargs K)
         if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = sample_direct<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+        const bool early = DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
+                                : sample_direct<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -209,6 +215,94 @@ __global__ __launch_bounds__(256, 5) void bdpt_direct_kernel(const bdpt_kargs K)
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* Dual-ray variant.  At every light-subpath vertex the reference traces two
+ * rays that leave the same primitive: the connection ray toward the eye vertex
+ * (kernel0.cl:705) and, if Russian roulette lets the walk go on, the bounce ray
+ * (:793).  Neither consumes a random number, so the bounce direction can be
+ * drawn first (the draw order :767, :787 is unchanged) and both rays can walk
+ * the primitive arrays together, one in each half of a 64-bit register pair:
+ * the scene record is read once for both and every add/mul/fma of the two
+ * tests issues as one v_pk_* instruction (bdpt_device2.h).                     */
+/* ------------------------------------------------------------------------- */
+
+template <bool AOV>
+BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
+                          uint32_t &hash, int eye_id[2], float col[4])
+{
+    const bdpt_dev_scene &S = K.scene;
+    rng_float(w, draws);                                                  /* :592, discarded */
+    clm_f3 dir = camera_ray(w, draws, K, xt, yt);
+    clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
+    Hit eye = closest_hit_direct(S, eye_pos, dir, 4, 0);                  /* :634 */
+    rays++;
+    if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
+
+    if (eye.type < 0) {                                                   /* :652-656 */
+        col[0] = col[1] = col[2] = col[3] = 0.0f;
+        return true;
+    }
+    const float4 eye_diffuse = S.surf[eye.surf * 2];
+    const float4 eye_emissive = S.surf[eye.surf * 2 + 1];
+    if (eye_emissive.w != 0.0f) {                                         /* :645-650 */
+        col[0] = eye_diffuse.x; col[1] = eye_diffuse.y; col[2] = eye_diffuse.z; col[3] = eye_diffuse.w;
+        return true;
+    }
+
+    clm_f3 vpos, vn;
+    sample_light(w, draws, K, vpos, vn);                                  /* :669 */
+    int vtype = K.light_origin_type, vidx = K.light_origin_index;
+
+    float full[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             /* :689 */
+    float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
+    float pre = K.pre_factor0;                                            /* :694 */
+    int taken = 0;
+    for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
+        const clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));      /* :699 */
+        const clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                 /* :761 */
+        const clm_f3 ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);   /* :767, :486 */
+        const float fate = rng_float(w, draws);                           /* :787 */
+        const bool go_on = !(fate > K.p_con);                             /* :788 */
+
+        i2 ot, oi;
+        ot.x = ot.y = vtype;
+        oi.x = oi.y = vidx;
+        const Hit2 h2 = closest_hit2(S, mk2(true, go_on), pack3(vpos, lpos), pack3(tdir, ldir), ot, oi);   /* :705 and :793 */
+        Hit vis;
+        vis.type = h2.type.x; vis.idx = h2.idx.x; vis.pos = comp3(h2.pos, 0); vis.n = comp3(h2.n, 0); vis.surf = h2.surf.x;
+        rays++;
+        if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
+        float contrib[4];
+        connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+        pre *= K.p_con;                                                   /* :745 */
+        if (!K.indirect_only || lti != 0) {                               /* :752-755 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) full[k] += contrib[k];
+        }
+        taken++;                                                          /* :757 */
+        if (!go_on) break;                                                /* :788 */
+
+        rays++;
+        if (AOV) hash = hash_step(hash, hit_id(h2.type.y, h2.idx.y));
+        if (h2.type.y < 0) break;                                         /* :812 */
+        const float4 nd = S.surf[h2.surf.y * 2];
+        const float4 ne = S.surf[h2.surf.y * 2 + 1];
+        if (ne.w != 0.0f) break;                                          /* :797-803 */
+        acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
+        vpos = comp3(h2.pos, 1); vn = comp3(h2.n, 1); vtype = h2.type.y; vidx = h2.idx.y;   /* :832 */
+    }
+
+    const float inv_taken = clm_div(1.0f, (float)taken);                  /* :846 */
+    const float ed[4] = {eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float c = K.light_emissive[k] * full[k] * inv_taken;
+        if (!K.indirect_only) c = c * ed[k];                              /* :844 / :846 */
+        col[k] = c;
+    }
+    return false;
+}
+
 /* Closest hit for caller-supplied rays: the unit the known-answer tests drive. */
 __global__ void bdpt_query_kernel(bdpt_dev_scene S, const float *rays, const int *origin, int n, int *out_id,
                                   float *out_pos, float *out_n)
@@ -253,15 +347,26 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 
 /* ---- launch wrappers ------------------------------------------------------ */
 
-hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+template <bool DUAL>
+static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
     dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
-    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true>), grid, block, 0, stream, K);
-    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false>), grid, block, 0, stream, K);
-    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true>), grid, block, 0, stream, K);
-    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false>), grid, block, 0, stream, K);
+    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true, DUAL>), grid, block, 0, stream, K);
+    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false, DUAL>), grid, block, 0, stream, K);
+    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true, DUAL>), grid, block, 0, stream, K);
+    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false, DUAL>), grid, block, 0, stream, K);
     return hipGetLastError();
+}
+
+hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    return launch_per_pixel<false>(K, aov, count, stream);
+}
+
+hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    return launch_per_pixel<true>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

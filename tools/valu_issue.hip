@@ -1,83 +1,124 @@
-// Issue cost of individual VALU instruction classes on one SIMD, 8 waves per SIMD,
-// independent registers (inline asm so the instruction stream is exactly what is written).
+// Issue cost of VALU instruction classes on gfx950, measured in shader cycles
+// (s_memtime) so that clock changes under load do not matter.  W waves per SIMD
+// run the same independent-instruction stream; the figure printed is
+// SIMD cycles per wave-instruction = loop cycles / (instructions per wave * waves per SIMD).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/valu_issue.hip -o tools/valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
+#include <algorithm>
 
 #define REP8(x) x x x x x x x x
-#define KERNEL(name, body)                                                             \
-    __global__ __launch_bounds__(256) void name(float *out, int iters, float a)        \
-    {                                                                                  \
-        float v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;                 \
-        for (int i = 0; i < iters; i++) {                                              \
-            asm volatile(REP8(body) : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "s"(a) : "vcc", "s40", "s41"); \
-        }                                                                              \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3;                \
+#define KERNEL(name, body)                                                                   \
+    __global__ __launch_bounds__(256) void name(float *out, unsigned long long *cyc, int iters, float a) \
+    {                                                                                        \
+        float v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7; \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                \
+        for (int i = 0; i < iters; i++) {                                                    \
+            asm volatile(REP8(body) : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(a) : "vcc", "s40", "s41"); \
+        }                                                                                    \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;  \
+        if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0; \
     }
 
-// each body = 4 instructions on 4 independent registers
-KERNEL(k_fma,   "v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_fma_f32 %2, %2, %4, %2\n v_fma_f32 %3, %3, %4, %3\n")
-KERNEL(k_mul,   "v_mul_f32 %0, %4, %0\n v_mul_f32 %1, %4, %1\n v_mul_f32 %2, %4, %2\n v_mul_f32 %3, %4, %3\n")
-KERNEL(k_fmac,  "v_fmac_f32 %0, %4, %1\n v_fmac_f32 %1, %4, %2\n v_fmac_f32 %2, %4, %3\n v_fmac_f32 %3, %4, %0\n")
-KERNEL(k_cmp,   "v_cmp_gt_f32 vcc, %4, %0\n v_cmp_gt_f32 vcc, %4, %1\n v_cmp_gt_f32 vcc, %4, %2\n v_cmp_gt_f32 vcc, %4, %3\n")
-KERNEL(k_cmp_s, "v_cmp_gt_f32 s[40:41], %4, %0\n v_cmp_gt_f32 s[40:41], %4, %1\n v_cmp_gt_f32 s[40:41], %4, %2\n v_cmp_gt_f32 s[40:41], %4, %3\n")
-KERNEL(k_cnd,   "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n")
-KERNEL(k_cmpcnd,"v_cmp_gt_f32 vcc, %4, %0\n s_nop 1\n v_cndmask_b32 %1, %1, %2, vcc\n v_cmp_gt_f32 vcc, %4, %2\n s_nop 1\n v_cndmask_b32 %3, %3, %0, vcc\n")
-KERNEL(k_rcp,   "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n")
-KERNEL(k_sqrt,  "v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n")
-KERNEL(k_dscale,"v_div_scale_f32 %0, vcc, %0, %1, %0\n v_div_scale_f32 %1, vcc, %1, %2, %1\n v_div_scale_f32 %2, vcc, %2, %3, %2\n v_div_scale_f32 %3, vcc, %3, %0, %3\n")
-KERNEL(k_dfixup,"v_div_fixup_f32 %0, %0, %1, %2\n v_div_fixup_f32 %1, %1, %2, %3\n v_div_fixup_f32 %2, %2, %3, %0\n v_div_fixup_f32 %3, %3, %0, %1\n")
-KERNEL(k_dfmas, "v_div_fmas_f32 %0, %0, %1, %2\n v_div_fmas_f32 %1, %1, %2, %3\n v_div_fmas_f32 %2, %2, %3, %0\n v_div_fmas_f32 %3, %3, %0, %1\n")
-KERNEL(k_min3,  "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_min3_f32 %2, %2, %3, %0\n v_min3_f32 %3, %3, %0, %1\n")
-KERNEL(k_rdlane,"v_readlane_b32 s40, %0, 3\n v_readlane_b32 s40, %1, 3\n v_readlane_b32 s40, %2, 3\n v_readlane_b32 s40, %3, 3\n")
-KERNEL(k_dep,   "v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %0, %0, %4, %0\n")
-KERNEL(k_saveex,"v_cmp_gt_f32 vcc, %4, %0\n s_and_saveexec_b64 s[40:41], vcc\n v_fma_f32 %1, %1, %4, %1\n s_or_b64 exec, exec, s[40:41]\n")
-KERNEL(k_salu,  "v_fma_f32 %0, %0, %4, %0\n s_mov_b32 s40, s41\n v_fma_f32 %1, %1, %4, %1\n s_mov_b32 s41, s40\n")
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define KERNEL64(name, body)                                                                 \
+    __global__ __launch_bounds__(256) void name(float *out, unsigned long long *cyc, int iters, float a) \
+    {                                                                                        \
+        f2v v0 = {(float)threadIdx.x, 1.f}, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f, v4 = v0 + 4.f, v5 = v0 + 5.f, v6 = v0 + 6.f, v7 = v0 + 7.f; \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                \
+        for (int i = 0; i < iters; i++) {                                                    \
+            asm volatile(REP8(body) : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(a) : "vcc", "s40", "s41"); \
+        }                                                                                    \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                \
+        f2v r = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;                                       \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r.x + r.y;                              \
+        if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0; \
+    }
 
-template <class K>
-void run(const char *name, K kern, float *out, int blocks, int instr_per_iter)
+// each body = 4 instructions on independent registers; %8 is an SGPR
+KERNEL(k_fma_v,  "v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %2, %2, %3, %2\n v_fma_f32 %4, %4, %5, %4\n v_fma_f32 %6, %6, %7, %6\n")
+KERNEL(k_fma_s,  "v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %6, %6, %8, %6\n")
+KERNEL(k_mul_v,  "v_mul_f32 %0, %1, %0\n v_mul_f32 %2, %3, %2\n v_mul_f32 %4, %5, %4\n v_mul_f32 %6, %7, %6\n")
+KERNEL(k_mul_s,  "v_mul_f32 %0, %8, %0\n v_mul_f32 %2, %8, %2\n v_mul_f32 %4, %8, %4\n v_mul_f32 %6, %8, %6\n")
+KERNEL(k_fmac,   "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %2, %3, %4\n v_fmac_f32 %4, %5, %6\n v_fmac_f32 %6, %7, %0\n")
+KERNEL64(k_pkfma_v,"v_pk_fma_f32 %0, %0, %1, %0\n v_pk_fma_f32 %2, %2, %3, %2\n v_pk_fma_f32 %4, %4, %5, %4\n v_pk_fma_f32 %6, %6, %7, %6\n")
+KERNEL64(k_pkmul_v,"v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %6, %6, %7\n")
+KERNEL64(k_pkadd_v,"v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %2, %2, %3\n v_pk_add_f32 %4, %4, %5\n v_pk_add_f32 %6, %6, %7\n")
+KERNEL(k_cmp,    "v_cmp_gt_f32 vcc, %8, %0\n v_cmp_gt_f32 vcc, %8, %1\n v_cmp_gt_f32 vcc, %8, %2\n v_cmp_gt_f32 vcc, %8, %3\n")
+KERNEL(k_cnd,    "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n")
+KERNEL(k_cnd_s,  "v_cndmask_b32 %0, %0, %1, s[40:41]\n v_cndmask_b32 %2, %2, %3, s[40:41]\n v_cndmask_b32 %4, %4, %5, s[40:41]\n v_cndmask_b32 %6, %6, %7, s[40:41]\n")
+KERNEL(k_cnd_ind,"v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n v_cndmask_b32 %6, %7, %1, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n")
+KERNEL(k_cmp_e64,"v_cmp_gt_f32 s[40:41], %0, %1\n v_cmp_gt_f32 s[40:41], %2, %3\n v_cmp_gt_f32 s[40:41], %4, %5\n v_cmp_gt_f32 s[40:41], %6, %7\n")
+KERNEL(k_cmp_vv, "v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %4, %5\n v_cmp_gt_f32 vcc, %6, %7\n")
+KERNEL(k_movs,   "v_mov_b32 %0, %8\n v_mov_b32 %2, %8\n v_mov_b32 %4, %8\n v_mov_b32 %6, %8\n")
+KERNEL(k_sub_s,  "v_sub_f32 %0, %8, %0\n v_sub_f32 %2, %8, %2\n v_sub_f32 %4, %8, %4\n v_sub_f32 %6, %8, %6\n")
+KERNEL(k_fma_c,  "v_fma_f32 %0, %0, 2.0, %0\n v_fma_f32 %2, %2, 2.0, %2\n v_fma_f32 %4, %4, 2.0, %4\n v_fma_f32 %6, %6, 2.0, %6\n")
+KERNEL(k_fmaak,  "v_fmaak_f32 %0, %0, %1, 0x3f000001\n v_fmaak_f32 %2, %2, %3, 0x3f000001\n v_fmaak_f32 %4, %4, %5, 0x3f000001\n v_fmaak_f32 %6, %6, %7, 0x3f000001\n")
+KERNEL(k_mov,    "v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %4, %5\n v_mov_b32 %6, %7\n")
+KERNEL(k_rcp,    "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n")
+KERNEL(k_dscale, "v_div_scale_f32 %0, vcc, %0, %1, %0\n v_div_scale_f32 %2, vcc, %2, %3, %2\n v_div_scale_f32 %4, vcc, %4, %5, %4\n v_div_scale_f32 %6, vcc, %6, %7, %6\n")
+KERNEL(k_dfmas,  "v_div_fmas_f32 %0, %0, %1, %2\n v_div_fmas_f32 %2, %2, %3, %4\n v_div_fmas_f32 %4, %4, %5, %6\n v_div_fmas_f32 %6, %6, %7, %0\n")
+KERNEL(k_rdlane, "v_readlane_b32 s40, %0, 3\n v_readlane_b32 s40, %1, 3\n v_readlane_b32 s40, %2, 3\n v_readlane_b32 s40, %3, 3\n")
+KERNEL(k_dep,    "v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n")
+KERNEL(k_mulo,   "v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %4, %4, %5\n v_mul_lo_u32 %6, %6, %7\n")
+KERNEL64(k_pkfma_s,"v_pk_fma_f32 %0, %0, s[40:41], %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, %2, s[40:41], %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %4, %4, s[40:41], %4 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %6, %6, s[40:41], %6 op_sel_hi:[1,0,1]\n")
+KERNEL64(k_f64fma, "v_fma_f64 %0, %0, %1, %0\n v_fma_f64 %2, %2, %3, %2\n v_fma_f64 %4, %4, %5, %4\n v_fma_f64 %6, %6, %7, %6\n")
+
+template <class Kn>
+void run(const char *name, Kn kern, float *out, unsigned long long *cyc, int cus, int waves_per_simd)
 {
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const int iters = 20000;
-    float best = 1e30f;
-    for (int rep = 0; rep < 3; rep++) {
-        (void)hipEventRecord(e0);
-        kern<<<blocks, 256>>>(out, iters, 1.0000001f);
-        (void)hipEventRecord(e1);
-        (void)hipEventSynchronize(e1);
-        float ms;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        best = ms < best ? ms : best;
-    }
-    // waves per SIMD = 8; cycles per wave-instruction per SIMD at 2.4 GHz
-    double wave_instr_per_simd = 8.0 * iters * instr_per_iter;
-    printf("%-10s %8.3f ms  %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n", name, best, best * 1e-3 * 2.4e9 / wave_instr_per_simd);
+    const int iters = 4000, blocks = cus * waves_per_simd;   /* 256 threads = 4 waves = one per SIMD */
+    kern<<<blocks, 256>>>(out, cyc, iters, 1.0000001f);
+    (void)hipDeviceSynchronize();
+    kern<<<blocks, 256>>>(out, cyc, iters, 1.0000001f);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 4);
+    (void)hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    double med = (double)h[h.size() / 2];
+    printf("%-12s waves/SIMD=%d: %.2f SIMD cycles per wave-instruction\n", name, waves_per_simd, med / (32.0 * iters * waves_per_simd));
 }
 
 int main()
 {
     hipDeviceProp_t p;
     (void)hipGetDeviceProperties(&p, 0);
-    const int blocks = p.multiProcessorCount * 8;
+    const int cus = p.multiProcessorCount;
     float *out;
-    (void)hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
-    run("fma", k_fma, out, blocks, 32);
-    run("mul", k_mul, out, blocks, 32);
-    run("fmac", k_fmac, out, blocks, 32);
-    run("cmp vcc", k_cmp, out, blocks, 32);
-    run("cmp sgpr", k_cmp_s, out, blocks, 32);
-    run("cndmask", k_cnd, out, blocks, 32);
-    run("cmp+cnd", k_cmpcnd, out, blocks, 32);   /* 4 VALU + 2 s_nop per body */
-    run("rcp", k_rcp, out, blocks, 32);
-    run("sqrt", k_sqrt, out, blocks, 32);
-    run("div_scale", k_dscale, out, blocks, 32);
-    run("div_fixup", k_dfixup, out, blocks, 32);
-    run("div_fmas", k_dfmas, out, blocks, 32);
-    run("min3", k_min3, out, blocks, 32);
-    run("readlane", k_rdlane, out, blocks, 32);
-    run("fma dep", k_dep, out, blocks, 32);
-    run("cmp+saveexec+fma+or (2 VALU)", k_saveex, out, blocks, 16);
-    run("fma+salu (2 VALU)", k_salu, out, blocks, 16);
+    unsigned long long *cyc;
+    (void)hipMalloc(&out, (size_t)cus * 8 * 256 * sizeof(float) * 2);
+    (void)hipMalloc(&cyc, (size_t)cus * 8 * 4 * sizeof(unsigned long long));
+    for (int w : {1, 2, 4, 8}) {
+        run("fma vgpr", k_fma_v, out, cyc, cus, w);
+        run("fma sgpr", k_fma_s, out, cyc, cus, w);
+        run("pk_fma", k_pkfma_v, out, cyc, cus, w);
+    }
+    const int w = 4;
+    run("mul vgpr", k_mul_v, out, cyc, cus, w);
+    run("mul sgpr", k_mul_s, out, cyc, cus, w);
+    run("fmac", k_fmac, out, cyc, cus, w);
+    run("pk_mul", k_pkmul_v, out, cyc, cus, w);
+    run("pk_add", k_pkadd_v, out, cyc, cus, w);
+    run("cmp", k_cmp, out, cyc, cus, w);
+    run("cndmask", k_cnd, out, cyc, cus, w);
+    run("cndmask sgpr", k_cnd_s, out, cyc, cus, w);
+    run("cndmask indep", k_cnd_ind, out, cyc, cus, w);
+    run("cmp e64 sgpr", k_cmp_e64, out, cyc, cus, w);
+    run("cmp vcc v,v", k_cmp_vv, out, cyc, cus, w);
+    run("mov from sgpr", k_movs, out, cyc, cus, w);
+    run("sub sgpr", k_sub_s, out, cyc, cus, w);
+    run("fma inline c", k_fma_c, out, cyc, cus, w);
+    run("fmaak literal", k_fmaak, out, cyc, cus, w);
+    run("pk_fma sgpr", k_pkfma_s, out, cyc, cus, w);
+    run("mov", k_mov, out, cyc, cus, w);
+    run("rcp", k_rcp, out, cyc, cus, w);
+    run("div_scale", k_dscale, out, cyc, cus, w);
+    run("div_fmas", k_dfmas, out, cyc, cus, w);
+    run("readlane", k_rdlane, out, cyc, cus, w);
+    run("fma dep", k_dep, out, cyc, cus, w);
+    run("mul_lo_u32", k_mulo, out, cyc, cus, w);
+    run("fma_f64", k_f64fma, out, cyc, cus, w);
     return 0;
 }

@@ -75,10 +75,14 @@ enum { BDPT_RNG_STREAM = 0, BDPT_RNG_STRIDED = 1 };
 enum { BDPT_LIGHT_ORIGIN_SELF = 0, BDPT_LIGHT_ORIGIN_NONE = 1 };
 enum { BDPT_FALLOFF_INV_SQ = 0, BDPT_FALLOFF_INV_SQ_PLUS_C = 1 };
 enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
-/* DIRECT: every ray walks the primitives on its own. DUAL: the connection ray and the
- * bounce ray of a light-subpath vertex walk them together, packed two to a register
- * pair. AUTO = DUAL. Results are identical. */
-enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2 };
+/* Kernel variants; all give identical results.
+ * DIRECT: every lane walks the primitive arrays with wave-uniform scalar loads.
+ * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
+ *         vertex walk them together, packed two to a register pair.
+ * LDS:    the workgroup keeps the whole scene in LDS (scenes up to 24 KB of records).
+ * TILED:  triangle records are staged through wave-private LDS tiles (any scene size).
+ * AUTO:   LDS when the scene fits, else TILED. */
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4 };
 
 typedef struct bdpt_params {
     int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */

@@ -218,7 +218,7 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown connection_falloff");
     if (p->accum_mode != BDPT_ACCUM_MEAN && p->accum_mode != BDPT_ACCUM_SUM)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
-    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_DUAL)
+    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_TILED)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->params = *p;
@@ -468,8 +468,15 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     if (aov && (rc = ensure_aovs(ctx)) != BDPT_OK) return rc;
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    if (ctx->params.kernel_variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
-    else HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
+    int variant = ctx->params.kernel_variant;
+    if (variant == BDPT_KERNEL_LDS && bdpt_lds_scene_bytes(K.scene) > BDPT_LDS_SCENE_MAX)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
+    /* AUTO: keep the scene in LDS when it fits, otherwise stage it through LDS tiles */
+    if (variant == BDPT_KERNEL_AUTO) variant = bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
+    if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
+    else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
+    else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
+    else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;
     ctx->num_samples += spp;                                              /* main.cpp:131 */

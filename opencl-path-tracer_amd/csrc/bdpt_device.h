@@ -221,6 +221,38 @@ BDPT_DEV void test_triangle(Best &b, float4 q0, float4 q1, float4 q2, float4 q3,
     best_consider(b, p, o, 2, i);                                                    /* :441-448 */
 }
 
+/*
+ * test_triangle for rays that scatter in all directions (connection and bounce
+ * rays).  Two changes of form, none of result:
+ *  - the back-face cull (:288) and the behind-the-origin cull (:292) are taken
+ *    together after the division: for such rays some lane of the wavefront
+ *    passes :288 for practically every triangle, so a separate branch there
+ *    only costs a compare and an exec-mask update per triangle;
+ *  - the origin primitive (:436) is not skipped up front but refused when it
+ *    would be accepted, which moves that compare out of the per-triangle path
+ *    into the one or two triangles per ray that are actually hit.
+ */
+BDPT_DEV void test_triangle_scattered(Best &b, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, float e2z, int i,
+                                      int skip, clm_f3 o, clm_f3 d)
+{
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float val = clm_dot3(d, n);                                                      /* :286 */
+    clm_f3 a = clm_make3(q0.w, q1.x, q1.y);
+    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
+    if (val > 0 || t < 0) return;                                                    /* :288, :292 */
+    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
+    clm_f3 e0 = clm_make3(q1.z, q1.w, q2.x);
+    clm_f3 c = clm_make3(q2.y, q2.z, q2.w);
+    clm_f3 e1 = clm_make3(q3.x, q3.y, q3.z);
+    clm_f3 bb = clm_make3(q3.w, q4.x, q4.y);
+    clm_f3 e2 = clm_make3(q4.z, q4.w, e2z);
+    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), e0), n);                          /* :298 */
+    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
+    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
+    if (dA < 0 || dB < 0 || dC < 0) return;                                          /* :304 */
+    if (i != skip) best_consider(b, p, o, 2, i);                                     /* :436, :441-448 */
+}
+
 /* kernel0.cl:452-473: surface id, shading normal of the winner, flip toward the ray */
 BDPT_DEV Hit finish_hit(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
 {

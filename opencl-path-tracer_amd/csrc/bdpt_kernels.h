@@ -13,6 +13,14 @@ hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStre
 /* The same work with the connection and bounce rays of a vertex traced together (packed FP32 math). */
 hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
+/* The same work with the whole scene resident in LDS (scenes up to BDPT_LDS_SCENE_MAX bytes of records). */
+#define BDPT_LDS_SCENE_MAX (24u * 1024u)
+size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S);
+hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
+/* The same work for scenes of any size: triangle records staged through wave-private LDS tiles. */
+hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
 /* Closest hit of n caller-supplied rays (6 floats each: origin, direction;
  * origin[2*i], origin[2*i+1] = primitive to skip or (4,0)). Device pointers. */
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

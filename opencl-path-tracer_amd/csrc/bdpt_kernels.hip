@@ -55,10 +55,70 @@ BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int
     return finish_hit(S, b, d);
 }
 
+/* ------------------------------------------------------------------------- */
+/* LDS-resident variant.  The workgroup copies the pre-laid-out scene records
+ * into LDS once (coalesced float4 loads), and every lane then walks them with
+ * wave-uniform ds_read_b128 (all lanes read one address: a broadcast, no bank
+ * conflicts).  The records land in VGPRs, so the arithmetic of the primitive
+ * tests has no scalar-register operand: on gfx950 a VALU instruction with an
+ * SGPR source issues in about 3.2 cycles per SIMD, one with VGPR sources only in
+ * 2.0 (tools/valu_issue.hip).                                                  */
+/* ------------------------------------------------------------------------- */
+
+extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | n_spheres | n_planes*2] */
+
+BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
+{
+    const int n_tri = S.n_triangles * BDPT_TRI_F4, n_sph = S.n_spheres, n_pln = S.n_planes * BDPT_PLN_F4;
+    for (int i = threadIdx.x; i < n_tri; i += blockDim.x) bdpt_lds[i] = S.tri[i];
+    for (int i = threadIdx.x; i < n_sph; i += blockDim.x) bdpt_lds[n_tri + i] = S.sph[i];
+    for (int i = threadIdx.x; i < n_pln; i += blockDim.x) bdpt_lds[n_tri + n_sph + i] = S.pln[i];
+    __syncthreads();
+}
+
+template <bool SCATTERED>
+BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx)
+{
+    Best b;
+    best_init(b);                                                         /* kernel0.cl:374, :384-385 */
+    const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
+    const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
+    const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
+    const int sph0 = S.n_triangles * BDPT_TRI_F4, pln0 = sph0 + S.n_spheres;
+    for (int i = 0; i < S.n_spheres; i++) {
+        const float4 s = bdpt_lds[sph0 + i];
+        if (i != skip_s) test_sphere(b, s, i, o, d);
+    }
+    for (int i = 0; i < S.n_planes; i++) {
+        const float4 q0 = bdpt_lds[pln0 + i * BDPT_PLN_F4], q1 = bdpt_lds[pln0 + i * BDPT_PLN_F4 + 1];
+        if (i != skip_p) test_plane(b, q0, q1, i, o, d);
+    }
+    for (int i = 0; i < S.n_triangles; i++) {
+        const int r = i * BDPT_TRI_F4;
+        const float4 q0 = bdpt_lds[r], q1 = bdpt_lds[r + 1], q2 = bdpt_lds[r + 2], q3 = bdpt_lds[r + 3],
+                     q4 = bdpt_lds[r + 4];
+        const float e2z = bdpt_lds[r + 5].x;
+        /* pin the whole record here: one LDS round trip per triangle instead of one per test stage */
+        asm volatile("" ::"v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(q4.x), "v"(e2z));
+        if (SCATTERED) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
+        else if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
+    }
+    return finish_hit(S, b, d);
+}
+
+enum { MODE_DIRECT = 0, MODE_DUAL = 1, MODE_LDS = 2 };
+
+/* SCATTERED: the rays of a wavefront point in unrelated directions (every ray but the eye ray) */
+template <int MODE, bool SCATTERED>
+BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx)
+{
+    return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
+}
+
 /* One sample (kernel0.cl:592-847).  Returns true when the reference would have
  * returned early (eye ray missed or hit a light, :645-656); col is then the raw
  * value it writes. */
-template <bool AOV>
+template <bool AOV, int MODE>
 BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                             uint32_t &hash, int eye_id[2], float col[4])
 {
@@ -66,7 +126,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     rng_float(w, draws);                                                  /* :592, discarded */
     clm_f3 dir = camera_ray(w, draws, K, xt, yt);
     clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
-    Hit eye = closest_hit_direct(S, eye_pos, dir, 4, 0);                  /* :634 */
+    Hit eye = trace_one<MODE, false>(S, eye_pos, dir, 4, 0);                  /* :634 */
     rays++;
     if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
 
@@ -91,7 +151,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     int taken = 0;
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
         clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));            /* :699 */
-        Hit vis = closest_hit_direct(S, vpos, tdir, vtype, vidx);         /* :705 */
+        Hit vis = trace_one<MODE, true>(S, vpos, tdir, vtype, vidx);         /* :705 */
         rays++;
         if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
         float contrib[4];
@@ -108,7 +168,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         float fate = rng_float(w, draws);                                 /* :787 */
         if (fate > K.p_con) break;                                        /* :788 */
 
-        Hit nxt = closest_hit_direct(S, lpos, ldir, vtype, vidx);         /* :793 */
+        Hit nxt = trace_one<MODE, true>(S, lpos, ldir, vtype, vidx);         /* :793 */
         rays++;
         if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
         if (nxt.type < 0) break;                                          /* :812 */
@@ -134,9 +194,10 @@ template <bool AOV>
 BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                           uint32_t &hash, int eye_id[2], float col[4]);   /* defined below */
 
-template <bool AOV, bool COUNT, bool DUAL>
+template <bool AOV, bool COUNT, int MODE>
 __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
 {
+    if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
     const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
@@ -164,8 +225,8 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
         if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                : sample_direct<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+        const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
+                                             : sample_direct<AOV, MODE>(K, xt, yt, w, draws, rays, hash, eye_id, col);
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -303,6 +364,248 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
     return false;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Tiled variant, for scenes too large to keep in LDS.  Each wavefront stages
+ * the triangle records through its own LDS buffer in tiles of BDPT_TILE_TRIS:
+ * all 64 lanes copy the tile with coalesced float4 loads (lane l copies float4
+ * l, l+64, ... of the tile), then every lane walks the tile with wave-uniform
+ * ds_read_b128 broadcasts, exactly as the LDS-resident variant walks the whole
+ * scene.  Two buffers per wavefront: the global loads of tile k+1 are issued
+ * before tile k is walked and written to the other buffer afterwards.
+ *
+ * The copy needs every lane of the wavefront, so the sample is written with a
+ * per-lane `alive` predicate instead of early exits: all lanes make the same
+ * sequence of closest-hit calls and a lane whose path has ended is masked.
+ * Buffers are private to a wavefront, so no workgroup barrier is involved and
+ * wavefronts of a workgroup run independently.                                 */
+/* ------------------------------------------------------------------------- */
+
+#define BDPT_TILE_TRIS 32
+#define BDPT_TILE_F4 (BDPT_TILE_TRIS * BDPT_TRI_F4)      /* 192 float4 = 3 per lane */
+
+BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool active, clm_f3 o, clm_f3 d, int otype,
+                               int oidx)
+{
+    Best b;
+    best_init(b);
+    const int lane = threadIdx.x & 63;
+    const int skip_s = otype == 0 ? oidx : -1;
+    const int skip_p = otype == 1 ? oidx : -1;
+    const int skip_t = otype == 2 ? oidx : -1;
+    if (active) {
+        for (int i = 0; i < S.n_spheres; i++) {
+            const float4 s = uload(S.sph, i);
+            if (i != skip_s) test_sphere(b, s, i, o, d);
+        }
+        for (int i = 0; i < S.n_planes; i++) {
+            const float4 q0 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 0), q1 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 1);
+            if (i != skip_p) test_plane(b, q0, q1, i, o, d);
+        }
+    }
+    const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
+    const size_t total_f4 = (size_t)(S.n_triangles + 1) * BDPT_TRI_F4;     /* the array is padded by one record */
+    float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */
+    auto fetch = [&](int tile) {
+        const size_t base = (size_t)tile * BDPT_TILE_F4 + lane;
+        r0 = S.tri[base < total_f4 ? base : 0];
+        r1 = S.tri[base + 64 < total_f4 ? base + 64 : 0];
+        r2 = S.tri[base + 128 < total_f4 ? base + 128 : 0];
+    };
+    if (n_tiles > 0) fetch(0);
+    for (int tile = 0; tile < n_tiles; tile++) {
+        float4 *buf = wave_lds + (tile & 1) * BDPT_TILE_F4;
+        buf[lane] = r0;
+        buf[lane + 64] = r1;
+        buf[lane + 128] = r2;
+        if (tile + 1 < n_tiles) fetch(tile + 1);
+        __builtin_amdgcn_wave_barrier();       /* LDS operations of one wavefront execute in order; this only pins the compiler */
+        if (active) {
+            const int first = tile * BDPT_TILE_TRIS;
+            const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
+            for (int j = 0; j < count; j++) {
+                const float4 *q = buf + j * BDPT_TRI_F4;
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+                const float e2z = q[5].x;
+                test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, first + j, skip_t, o, d);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return finish_hit(S, b, d);
+}
+
+/* sample_direct with every early exit turned into the `alive` predicate (see above) */
+template <bool AOV>
+BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, float xt, float yt, uint32_t &w,
+                           uint32_t &draws, uint32_t &rays, uint32_t &hash, int eye_id[2], float col[4])
+{
+    const bdpt_dev_scene &S = K.scene;
+    clm_f3 dir = clm_make3(0.f, 0.f, 1.f), eye_pos = dir;
+    if (live) {
+        rng_float(w, draws);                                              /* :592, discarded */
+        dir = camera_ray(w, draws, K, xt, yt);
+        eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));                 /* :632 */
+    }
+    Hit eye = closest_hit_tiled(S, wave_lds, live, eye_pos, dir, 4, 0);   /* :634 */
+    bool early = false;
+    float4 eye_diffuse = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        rays++;
+        if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
+        if (eye.type < 0) {                                               /* :652-656 */
+            col[0] = col[1] = col[2] = col[3] = 0.0f;
+            early = true;
+        } else {
+            eye_diffuse = S.surf[eye.surf * 2];
+            if (S.surf[eye.surf * 2 + 1].w != 0.0f) {                     /* :645-650 */
+                col[0] = eye_diffuse.x; col[1] = eye_diffuse.y; col[2] = eye_diffuse.z; col[3] = eye_diffuse.w;
+                early = true;
+            }
+        }
+    }
+    bool alive = live && !early;
+    clm_f3 vpos = clm_make3(0.f, 0.f, 0.f), vn = clm_make3(0.f, 0.f, 1.f);
+    if (alive) sample_light(w, draws, K, vpos, vn);                       /* :669 */
+    int vtype = K.light_origin_type, vidx = K.light_origin_index;
+
+    float full[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             /* :689 */
+    float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
+    float pre = K.pre_factor0;                                            /* :694 */
+    int taken = 0;
+    for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;               /* wave-uniform */
+        clm_f3 tdir = clm_make3(0.f, 0.f, 1.f);
+        if (alive) tdir = clm_normalize3(clm_sub3(eye.pos, vpos));        /* :699 */
+        Hit vis = closest_hit_tiled(S, wave_lds, alive, vpos, tdir, vtype, vidx);   /* :705 */
+        clm_f3 lpos = vpos, ldir = tdir;
+        if (alive) {
+            rays++;
+            if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
+            float contrib[4];
+            connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+            if (!K.indirect_only || lti != 0) {                           /* :752-755 */
+#pragma unroll
+                for (int k = 0; k < 4; k++) full[k] += contrib[k];
+            }
+            taken++;                                                      /* :757 */
+            lpos = clm_mad3(0.00001f, vn, vpos);                          /* :761 */
+            ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);            /* :767, :486 */
+            const float fate = rng_float(w, draws);                       /* :787 */
+            if (fate > K.p_con) alive = false;                            /* :788 */
+        }
+        pre *= K.p_con;                                                   /* :745 */
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        Hit nxt = closest_hit_tiled(S, wave_lds, alive, lpos, ldir, vtype, vidx);   /* :793 */
+        if (alive) {
+            rays++;
+            if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
+            if (nxt.type < 0) {                                           /* :812 */
+                alive = false;
+            } else {
+                const float4 nd = S.surf[nxt.surf * 2];
+                if (S.surf[nxt.surf * 2 + 1].w != 0.0f) {                 /* :797-803 */
+                    alive = false;
+                } else {
+                    acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
+                    vpos = nxt.pos; vn = nxt.n; vtype = nxt.type; vidx = nxt.idx;     /* :832 */
+                }
+            }
+        }
+    }
+    if (live && !early) {
+        const float inv_taken = clm_div(1.0f, (float)taken);              /* :846 */
+        const float ed[4] = {eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float c = K.light_emissive[k] * full[k] * inv_taken;
+            if (!K.indirect_only) c = c * ed[k];                          /* :844 / :846 */
+            col[k] = c;
+        }
+    }
+    return early;
+}
+
+template <bool AOV, bool COUNT>
+__global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
+{
+    __shared__ float4 tiles[4][2 * BDPT_TILE_F4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 *wave_lds = tiles[wv];
+    const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
+    const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
+    const bool inside = x < K.rx0 + K.rw && y < K.ry0 + K.rh;             /* lanes outside still help copy tiles */
+    const size_t pix = inside ? (size_t)y * K.width + x : 0;
+
+    float4 a4 = inside ? K.accum[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[4] = {a4.x, a4.y, a4.z, a4.w};
+    const uint32_t seed = inside ? K.seed_w[pix] : 1u;
+    uint32_t w = seed;
+    uint32_t stride_state = 0;
+    if (K.rng_mode == BDPT_RNG_STRIDED) stride_state = seed * pow_u32(kSampleStride, K.first_sample);
+
+    uint32_t draws = 0, rays = 0, hash = 0;
+    if (AOV && inside) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
+    unsigned long long c_rays = 0, c_full = 0, c_early = 0;
+    int eye_id[2] = {-1, -1};
+    float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float xt = 0.f, yt = 0.f;
+    if (inside) pixel_coord(K, x, y, xt, yt);
+
+    bool live = inside;                                   /* false once a STREAM-mode pixel has frozen (kernel0.cl:645-656) */
+    for (int s = 0; s < K.spp; s++) {
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+        const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
+        if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
+        const uint32_t w_before = w;
+        const uint32_t rays_before = rays;
+        const bool early = sample_tiled<AOV>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
+        if (!live) continue;
+        if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
+        if (early && K.rng_mode == BDPT_RNG_STREAM) {
+            w = w_before;
+            acc[0] = col[0]; acc[1] = col[1]; acc[2] = col[2]; acc[3] = col[3];
+            const int rest = K.spp - 1 - s;
+            if (AOV) {
+                const uint32_t id = hit_id(eye_id[0], eye_id[1]);
+                for (int r = 0; r < rest; r++) hash = hash_step(hash, id);
+                draws += 3u * (uint32_t)rest;
+                rays += (uint32_t)rest;
+            }
+            if (COUNT) c_early += (unsigned long long)rest;
+            live = false;
+            continue;
+        }
+        if (n == 0) {                                                     /* :855 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = col[k];
+        } else if (K.accum_mode == BDPT_ACCUM_SUM) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = acc[k] + col[k];
+        } else {                                                          /* :854 */
+            const float s1 = clm_div((float)n, (float)(n + 1));
+            const float s2 = clm_div(1.0f, (float)(n + 1));
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = clm_fma(col[k], s2, acc[k] * s1);
+        }
+    }
+    if (!inside) return;
+    K.accum[pix] = make_float4(acc[0], acc[1], acc[2], acc[3]);           /* :863 */
+    if (K.rng_mode == BDPT_RNG_STREAM) K.seed_w[pix] = w;                 /* :861 */
+    if (AOV) {
+        K.aov_eye_hit[pix * 2] = eye_id[0];
+        K.aov_eye_hit[pix * 2 + 1] = eye_id[1];
+        K.aov_hit_hash[pix] = hash;
+        K.aov_radiance[pix] = make_float4(col[0], col[1], col[2], col[3]);
+        K.aov_rng_draws[pix] = draws;
+        K.aov_rays[pix] = rays;
+    }
+    if (COUNT) {
+        atomicAdd(&K.counters[0], c_rays);
+        atomicAdd(&K.counters[1], c_full);
+        atomicAdd(&K.counters[2], c_early);
+    }
+}
+
 /* Closest hit for caller-supplied rays: the unit the known-answer tests drive. */
 __global__ void bdpt_query_kernel(bdpt_dev_scene S, const float *rays, const int *origin, int n, int *out_id,
                                   float *out_pos, float *out_n)
@@ -347,26 +650,52 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 
 /* ---- launch wrappers ------------------------------------------------------ */
 
-template <bool DUAL>
+template <int MODE>
 static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
     dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
-    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true, DUAL>), grid, block, 0, stream, K);
-    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false, DUAL>), grid, block, 0, stream, K);
-    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true, DUAL>), grid, block, 0, stream, K);
-    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false, DUAL>), grid, block, 0, stream, K);
+    size_t lds = 0;
+    if (MODE == bdpt::MODE_LDS) {
+        lds = bdpt_lds_scene_bytes(K.scene);
+        if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
+    }
+    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true, MODE>), grid, block, lds, stream, K);
+    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false, MODE>), grid, block, lds, stream, K);
+    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true, MODE>), grid, block, lds, stream, K);
+    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false, MODE>), grid, block, lds, stream, K);
     return hipGetLastError();
+}
+
+size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S)
+{
+    return ((size_t)S.n_triangles * BDPT_TRI_F4 + (size_t)S.n_spheres + (size_t)S.n_planes * BDPT_PLN_F4) * sizeof(float4);
 }
 
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
-    return launch_per_pixel<false>(K, aov, count, stream);
+    return launch_per_pixel<bdpt::MODE_DIRECT>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
-    return launch_per_pixel<true>(K, aov, count, stream);
+    return launch_per_pixel<bdpt::MODE_DUAL>(K, aov, count, stream);
+}
+
+hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    return launch_per_pixel<bdpt::MODE_LDS>(K, aov, count, stream);
+}
+
+hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
+    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<true, true>), grid, block, 0, stream, K);
+    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<true, false>), grid, block, 0, stream, K);
+    else if (count) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<false, true>), grid, block, 0, stream, K);
+    else hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<false, false>), grid, block, 0, stream, K);
+    return hipGetLastError();
 }
 
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

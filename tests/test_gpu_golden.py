@@ -7,10 +7,12 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 @pytest.mark.parametrize("case", gu.RENDER_CASES)
-def test_render_matches_golden(bdpt, case):
+def test_render_matches_golden(bdpt, case, variant):
     g = gu.load(case)
     scene, p, W, H, spp, off = gu.unpack(bdpt, g)
+    p.kernel_variant = variant
     with bdpt.Context(W, H) as ctx:
         ctx.set_params(p)
         ctx.upload_scene(scene)

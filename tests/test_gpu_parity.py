@@ -138,11 +138,15 @@ def test_near_ties_resolve_like_the_reference_order(bdpt, oracle):
     ctx.close()
 
 
-def test_cornell_per_sample_parity_stream_mode(bdpt, oracle):
+VARIANTS = [1, 2, 3, 4]   # DIRECT, DUAL, LDS, TILED: every kernel variant must give the same bits
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_cornell_per_sample_parity_stream_mode(bdpt, oracle, variant):
     """64x64 Cornell, 16 samples one launch each: ids, hashes, radiance, accumulator and seeds after every sample."""
     scene = bdpt.Scene.cornell()
     W = H = 64
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, kernel_variant=variant)
     for s in range(16):
         ctx.render(1)
         oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
@@ -151,11 +155,12 @@ def test_cornell_per_sample_parity_stream_mode(bdpt, oracle):
     ctx.close()
 
 
-def test_batched_launch_equals_sample_by_sample(bdpt, oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_batched_launch_equals_sample_by_sample(bdpt, oracle, variant):
     """One launch of 24 samples gives the bits of 24 one-sample launches (the oracle runs them one by one)."""
     scene = bdpt.Scene.cornell()
     W, H = 96, 56
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=99)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=99, kernel_variant=variant)
     ctx.render(24)
     for _ in range(24):
         oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
@@ -166,31 +171,34 @@ def test_batched_launch_equals_sample_by_sample(bdpt, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("scene_name,W,H", [("cornell_planes", 64, 48), ("outdoor", 80, 48)])
-def test_other_scenes_parity(bdpt, oracle, scene_name, W, H):
+def test_other_scenes_parity(bdpt, oracle, scene_name, W, H, variant):
     scene = getattr(bdpt.Scene, scene_name)()
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=3)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=3, kernel_variant=variant)
     ctx.render(8)
     oracle.render(st, scene, scene.camera, p, 8, n_threads=8)
     _compare(bdpt, ctx, st, scene_name + ":")
     ctx.close()
 
 
-def test_soup_scene_parity(bdpt, oracle):
-    """Cornell + 3000 soup triangles, 32x32 x 2 spp (the exhaustive search over many primitives)."""
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+def test_soup_scene_parity(bdpt, oracle, variant):
+    """Cornell + 3000 soup triangles, 32x32 x 2 spp (the exhaustive search over many primitives; AUTO must pick TILED)."""
     scene = bdpt.Scene.soup(3000)
-    ctx, st, p = _pair(bdpt, oracle, scene, 32, 32, seed=5)
+    ctx, st, p = _pair(bdpt, oracle, scene, 32, 32, seed=5, kernel_variant=variant)
     ctx.render(2)
     oracle.render(st, scene, scene.camera, p, 2, n_threads=8)
     _compare(bdpt, ctx, st, "soup:")
     ctx.close()
 
 
-def test_strided_mode_and_sample_split(bdpt, oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_strided_mode_and_sample_split(bdpt, oracle, variant):
     """STRIDED + SUM: two contexts rendering samples [0,6) and [6,12) add up to one context rendering [0,12)."""
     scene = bdpt.Scene.cornell()
     W, H = 64, 40
-    kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=variant)
     ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=11, **kw)
     ctx.render(12)
     oracle.render(st, scene, scene.camera, p, 12, n_threads=8)
@@ -210,10 +218,11 @@ def test_strided_mode_and_sample_split(bdpt, oracle):
     np.testing.assert_allclose(parts[0] + parts[1], whole, rtol=1e-5, atol=1e-6)
 
 
-def test_region_renders_only_its_pixels(bdpt, oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_region_renders_only_its_pixels(bdpt, oracle, variant):
     scene = bdpt.Scene.cornell()
     W, H = 64, 64
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=21)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=21, kernel_variant=variant)
     region = (19, 7, 30, 41)   # deliberately not a multiple of the 8x8 wavefront tile
     ctx.set_region(*region)
     ctx.render(3)
@@ -267,3 +276,15 @@ def test_error_paths(bdpt):
     ctx.close()
     with pytest.raises(bdpt.BdptError):
         bdpt.Context(16, 16, device=4096)
+
+
+def test_lds_variant_refuses_a_scene_that_does_not_fit(bdpt):
+    scene = bdpt.Scene.soup(3000)
+    ctx = bdpt.Context(16, 16)
+    ctx.set_params(kernel_variant=bdpt.KERNEL_LDS)
+    ctx.upload_scene(scene)
+    ctx.upload_seeds(bdpt.make_seeds(16, 16))
+    ctx.set_camera(scene.camera)
+    with pytest.raises(bdpt.BdptError):
+        ctx.render(1)
+    ctx.close()

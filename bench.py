@@ -30,6 +30,19 @@ F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flo
 F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
 
 
+def hbm_traffic_bytes(width, height):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled as the
+    gfx950 correction for wide coalesced reads, plus WRITE_SIZE; both are independent of spp), or None when no pass
+    was recorded for this image size."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec.get("%dx%d" % (width, height), {}).get("bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,6 +52,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per rank per step")
     ap.add_argument("--kernel", type=int, default=0, help="bdpt_params.kernel_variant (0 auto)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2: Cornell box (the headline configuration); c3: outdoor sphere arrangement, 3840x2160 unless "
+                         "--width/--height are given; c4: Cornell box + 100k-triangle soup")
+    ap.add_argument("--soup", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -63,8 +80,15 @@ def main():
 
     import bdpt
 
+    if args.workload == "c3" and (args.width, args.height) == (1920, 1080):
+        args.width, args.height = 3840, 2160
     W, H, SPP = args.width, args.height, args.spp
-    scene = bdpt.Scene.cornell()
+    if args.workload == "c2":
+        scene, scene_name = bdpt.Scene.cornell(), "Cornell box (3 spheres + 12 triangles)"
+    elif args.workload == "c3":
+        scene, scene_name = bdpt.Scene.outdoor(), "outdoor sphere arrangement (6 spheres, no walls)"
+    else:
+        scene, scene_name = bdpt.Scene.soup(args.soup), "Cornell box + %d-triangle soup" % args.soup
     ctx = bdpt.Context(W, H, device=local_rank)
     ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel))
     ctx.upload_scene(scene)
@@ -120,7 +144,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "Cornell box (3 spheres + 12 triangles), %dx%d, %d spp per GPU per step, exhaustive closest hit" % (W, H, SPP),
+            "workload": "%s, %dx%d, %d spp per GPU per step, exhaustive closest hit" % (scene_name, W, H, SPP),
             "rng_mode": "strided", "split": "samples per pixel" if world > 1 else "none",
             "combine": "RCCL reduce(sum) of %dx%dx4 f32 to rank 0" % (W, H) if world > 1 else "none",
         },
@@ -140,7 +164,7 @@ def main():
         achieved = flops / avg_s / 1e12
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": hbm_traffic_bytes(W, H),
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
             "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
         }

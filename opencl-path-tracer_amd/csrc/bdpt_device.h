@@ -308,6 +308,67 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
     for (int k = 0; k < 4; k++) out[k] = acc[k] * sf * df * inv_imp;                 /* :741 */
 }
 
+/*
+ * Order in which a launch takes the samples of a pixel.
+ *
+ * STREAM mode and MEAN accumulation are sequential by definition.  In STRIDED
+ * mode every sample has its own start state, and the Russian-roulette draws of
+ * a sample (the draw after each cone sample, kernel0.cl:787) depend on that
+ * state alone, so the number of light-subpath vertices roulette allows -- its
+ * class, 1..max_l -- is known before the sample is traced.  A wavefront walks
+ * the light subpaths of its 64 pixels in lock-step and pays for the longest of
+ * them; taking samples class by class (longest first, sample index ascending
+ * within a class) lets all lanes run subpaths of equal length at the same time.
+ * With SUM accumulation this order is simply the order of the additions; it is
+ * part of the definition of a STRIDED + SUM launch (the CPU oracle adds in the
+ * same order) and changes no sample.
+ */
+struct SampleCursor {
+    int cls;            /* class being collected (reorder) */
+    int s;              /* next sample index to examine */
+    uint32_t st, st0;   /* STRIDED: start state of sample s, of sample 0 */
+};
+
+BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
+{
+    for (int k = 0; k + 1 < K.max_l; k++) {
+        const float fate = (float)(start_state * K.fate_mul[k]) * 0x1p-32f;
+        if (fate > K.p_con) return k + 1;                                            /* :788 */
+    }
+    return K.max_l;
+}
+
+BDPT_DEV void cursor_init(SampleCursor &c, const bdpt_kargs &K, uint32_t seed)
+{
+    c.cls = K.max_l;
+    c.s = 0;
+    c.st0 = (K.rng_mode == BDPT_RNG_STRIDED) ? seed * pow_u32(kSampleStride, K.first_sample) : 0u;
+    c.st = c.st0;
+}
+
+/* false when the launch has no more samples for this pixel; otherwise start = start state (STRIDED) */
+BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, uint32_t &start)
+{
+    if (!K.reorder) {
+        if (c.s >= K.spp) return false;
+        start = c.st;
+        c.st *= kSampleStride;
+        c.s++;
+        return true;
+    }
+    for (;;) {
+        while (c.s < K.spp) {
+            const uint32_t st = c.st;
+            c.st *= kSampleStride;
+            c.s++;
+            if (roulette_class(K, st) == c.cls) { start = st; return true; }
+        }
+        if (--c.cls < 1) return false;
+        c.s = 0;
+        c.st = c.st0;
+    }
+}
+
 /* one link of the per-pixel hit-id chain (the additive constant keeps a run of
  * zero ids from pinning the chain at zero) */
 BDPT_DEV uint32_t hash_step(uint32_t h, uint32_t id) { return (h ^ id) * 16777619u + 0x9E3779B9u; }

@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
     float acc[4] = {a4.x, a4.y, a4.z, a4.w};
     const uint32_t seed = K.seed_w[pix];
     uint32_t w = seed;
-    uint32_t stride_state = 0;
-    if (K.rng_mode == BDPT_RNG_STRIDED) stride_state = seed * pow_u32(kSampleStride, K.first_sample);
+    SampleCursor cur;
+    cursor_init(cur, K, seed);
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
@@ -220,9 +220,10 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
     float xt, yt;
     pixel_coord(K, x, y, xt, yt);
 
-    for (int s = 0; s < K.spp; s++) {
+    uint32_t start;
+    for (int s = 0; cursor_next(cur, K, start); s++) {                    /* s counts the samples taken so far */
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
-        if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
+        if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
@@ -540,8 +541,8 @@ __global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
     float acc[4] = {a4.x, a4.y, a4.z, a4.w};
     const uint32_t seed = inside ? K.seed_w[pix] : 1u;
     uint32_t w = seed;
-    uint32_t stride_state = 0;
-    if (K.rng_mode == BDPT_RNG_STRIDED) stride_state = seed * pow_u32(kSampleStride, K.first_sample);
+    SampleCursor cur;
+    cursor_init(cur, K, seed);
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV && inside) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
@@ -551,11 +552,13 @@ __global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
     float xt = 0.f, yt = 0.f;
     if (inside) pixel_coord(K, x, y, xt, yt);
 
-    bool live = inside;                                   /* false once a STREAM-mode pixel has frozen (kernel0.cl:645-656) */
-    for (int s = 0; s < K.spp; s++) {
+    bool live = inside;                                   /* false once the pixel has no more samples in this launch */
+    for (int s = 0;; s++) {                                               /* s counts the samples taken so far */
+        uint32_t start = 0;
+        if (live) live = cursor_next(cur, K, start);
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
-        if (K.rng_mode == BDPT_RNG_STRIDED) { w = stride_state; stride_state *= kSampleStride; }
+        if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = sample_tiled<AOV>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);

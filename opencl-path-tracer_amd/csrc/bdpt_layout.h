@@ -75,6 +75,11 @@ struct bdpt_kargs {
     int falloff;
     float falloff_c;
     int accum_mode;
+    /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
+     * gives their light subpath (see sample_cursor in bdpt_device.h); fate_mul[k] = 48271^(9+4k)
+     * turns a sample's start state into the state of its k-th roulette draw */
+    int reorder;
+    uint32_t fate_mul[8];
 };
 
 #endif

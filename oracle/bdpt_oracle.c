@@ -440,6 +440,20 @@ static uint32_t pow_u32(uint32_t base, uint32_t e)
     return r;
 }
 
+/* Class of a STRIDED sample: the number of light-subpath vertices Russian roulette allows it
+ * (the draws at kernel0.cl:787 are draws 9, 13, 17, ... of the sample and depend on nothing else). */
+static int roulette_class(const bdpt_params *P, uint32_t start_state)
+{
+    uint32_t w = start_state;
+    for (int j = 0; j < 9; j++) w *= 48271u;
+    for (int k = 0; k + 1 < P->max_light_bounces; k++) {
+        float fate = clm_div((float)w, 4294967296.0f);
+        if (fate > P->p_continue) return k + 1;
+        for (int j = 0; j < 4; j++) w *= 48271u;
+    }
+    return P->max_light_bounces;
+}
+
 static void render_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt[3])
 {
     const bdpt_params *P = J->params;
@@ -454,11 +468,20 @@ static void render_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt
     Sample S;
     memset(&S, 0, sizeof S);
 
-    for (int s = 0; s < J->spp; s++) {
+    /* A STRIDED + SUM call adds its samples class by class (longest roulette class first, sample
+     * index ascending within a class); every other combination takes them in index order. */
+    const int reorder = P->rng_mode == BDPT_RNG_STRIDED && P->accum_mode == BDPT_ACCUM_SUM && P->max_light_bounces <= 8;
+    const uint32_t stride = pow_u32(48271u, 32u);
+    int taken = 0;
+    for (int cls = reorder ? P->max_light_bounces : 1; cls >= 1; cls--)
+    for (int si = 0; si < J->spp; si++) {
+        const uint32_t start = J->seeds[sidx] * pow_u32(stride, (uint32_t)(J->sample_offset + J->num_samples + si));
+        if (reorder && roulette_class(P, start) != cls) continue;
+        const int s = taken++;
         int n = J->num_samples + s;                                       /* :588 */
         uint32_t rays0 = L.rays;
         if (P->rng_mode == BDPT_RNG_STRIDED)
-            L.w = J->seeds[sidx] * pow_u32(pow_u32(48271u, 32u), (uint32_t)(J->sample_offset + n));
+            L.w = start;
         else
             L.w = J->seeds[sidx];
 

@@ -219,6 +219,27 @@ def test_strided_mode_and_sample_split(bdpt, oracle, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_strided_sum_launch_adds_by_roulette_class(bdpt, oracle, variant):
+    """A 40-sample STRIDED + SUM launch: the device takes the samples class by class; so does the oracle, bit for bit.
+    The classes only reorder the additions: the sum matches the index-ordered MEAN of the same samples to rounding."""
+    scene = bdpt.Scene.cornell()
+    W, H, SPP = 64, 40, 40
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=17, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM,
+                       kernel_variant=variant)
+    ctx.set_sample_offset(3)
+    ctx.render(SPP)
+    oracle.render(st, scene, scene.camera, p, SPP, sample_offset=3, n_threads=8)
+    _compare(bdpt, ctx, st, "class-ordered sum:")
+    total = ctx.read_accum()
+    ctx.close()
+    ctx2, st2, p2 = _pair(bdpt, oracle, scene, W, H, seed=17, rng_mode=bdpt.RNG_STRIDED, kernel_variant=variant)
+    ctx2.set_sample_offset(3)
+    ctx2.render(SPP)
+    np.testing.assert_allclose(total / SPP, ctx2.read_accum(), rtol=2e-5, atol=1e-6)
+    ctx2.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_region_renders_only_its_pixels(bdpt, oracle, variant):
     scene = bdpt.Scene.cornell()
     W, H = 64, 64

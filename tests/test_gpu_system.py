@@ -55,7 +55,8 @@ def test_full_frame_properties_at_benchmark_size(bdpt):
     a, _ = _render(bdpt, scene, W, H, 8, 1, **kw)
     b, _ = _render(bdpt, scene, W, H, 8, 1, **kw)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))              # run-to-run bit-identical
-    # the same 8 samples as two launches of 4 continue the same sums
+    # the same 8 samples as two launches of 4 continue the same sums (a STRIDED + SUM launch adds its samples
+    # grouped by roulette class, so the two orders of addition differ by fp32 rounding only)
     with bdpt.Context(W, H) as ctx:
         ctx.set_params(bdpt.default_params(**kw))
         ctx.upload_scene(scene)
@@ -64,7 +65,7 @@ def test_full_frame_properties_at_benchmark_size(bdpt):
         ctx.render(4)
         ctx.render(4)
         c = ctx.read_accum()
-    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
     # every kernel variant gives the same frame
     for variant in (bdpt.KERNEL_DIRECT, bdpt.KERNEL_TILED):
         v, _ = _render(bdpt, scene, W, H, 8, 1, kernel_variant=variant, **kw)

@@ -454,13 +454,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.falloff = P.connection_falloff;
     K.falloff_c = P.falloff_c;
     K.accum_mode = P.accum_mode;
-    K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.max_light_bounces <= 8) ? 1 : 0;
-    uint32_t a = 1u;
-    for (int j = 0; j < 9; j++) a *= 48271u;                              /* draw 9 of a sample is its first roulette draw */
-    for (int k = 0; k < 8; k++) {
-        K.fate_mul[k] = a;
-        a *= 48271u * 48271u * 48271u * 48271u;                           /* four draws per light-subpath vertex */
-    }
+    K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM) ? 1 : 0;
     return BDPT_OK;
 }
 

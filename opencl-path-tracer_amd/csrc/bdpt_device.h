@@ -324,49 +324,101 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
  * same order) and changes no sample.
  */
 struct SampleCursor {
-    int cls;            /* class being collected (reorder) */
-    int s;              /* next sample index to examine */
-    uint32_t st, st0;   /* STRIDED: start state of sample s, of sample 0 */
+    int cls;                /* class being collected (reorder) */
+    int head;               /* next sample index to examine */
+    uint32_t st_head;       /* STRIDED: start state of sample head */
+    uint32_t pending;       /* reorder: bit i set = sample head-1-i is of class cls and not traced yet */
 };
 
+/* 48271^e mod 2^32 */
+BDPT_DEV constexpr uint32_t lcg_pow(int e)
+{
+    uint32_t m = 1u;
+    for (int i = 0; i < e; i++) m *= 48271u;
+    return m;
+}
+
+/* Number of light-subpath vertices roulette allows a sample; same cost for every lane.  A sample
+ * draws 9 numbers before its first roulette draw (2 pixel jitter, 3 light point, 4 first cone sample)
+ * and 4 between one roulette draw and the next, so draw k is the start state times 48271^(9+4k). */
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
+    int cls = K.max_l;
+    uint32_t x = start_state * lcg_pow(9);
     for (int k = 0; k + 1 < K.max_l; k++) {
-        const float fate = (float)(start_state * K.fate_mul[k]) * 0x1p-32f;
-        if (fate > K.p_con) return k + 1;                                            /* :788 */
+        const float fate = (float)x * 0x1p-32f;
+        cls = (fate > K.p_con && cls == K.max_l) ? k + 1 : cls;                      /* :788 */
+        x *= lcg_pow(4);
     }
-    return K.max_l;
+    return cls;
+}
+
+/* start state of the first sample of this launch (STRIDED) */
+BDPT_DEV uint32_t cursor_first_state(const bdpt_kargs &K, uint32_t seed)
+{
+    return (K.rng_mode == BDPT_RNG_STRIDED) ? seed * pow_u32(kSampleStride, K.first_sample) : 0u;
 }
 
 BDPT_DEV void cursor_init(SampleCursor &c, const bdpt_kargs &K, uint32_t seed)
 {
     c.cls = K.max_l;
-    c.s = 0;
-    c.st0 = (K.rng_mode == BDPT_RNG_STRIDED) ? seed * pow_u32(kSampleStride, K.first_sample) : 0u;
-    c.st = c.st0;
+    c.head = 0;
+    c.st_head = cursor_first_state(K, seed);
+    c.pending = 0u;
 }
 
-/* false when the launch has no more samples for this pixel; otherwise start = start state (STRIDED) */
-BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, uint32_t &start)
+/* multiplicative inverse of kSampleStride mod 2^32, raised to 2^j */
+BDPT_DEV constexpr uint32_t stride_inv_pow2(int j)
+{
+    uint32_t inv = kSampleStride;                       /* Newton: inv <- inv * (2 - stride * inv) doubles the correct low bits */
+    for (int i = 0; i < 5; i++) inv *= 2u - kSampleStride * inv;
+    for (int i = 0; i < j; i++) inv *= inv;
+    return inv;
+}
+static_assert(stride_inv_pow2(0) * kSampleStride == 1u, "stride inverse");
+
+/*
+ * false when the launch has no more samples for this pixel; otherwise start = start state (STRIDED).
+ * seed_w = the pixel's seed word, wanted again when a lane restarts at sample 0 for the next class.
+ *
+ * In a reordered launch a lane finds its next sample of the current class by classifying sample
+ * indices ahead of the last one it traced.  The lanes of a wavefront do this together, one index per
+ * lane per round, until every lane has a sample to trace; a lane that already has one keeps
+ * classifying (up to 32 indices past its oldest untraced sample) and remembers what it finds in
+ * `pending`, so that it seldom is the lane the others wait for.
+ */
+BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *seed_w, uint32_t &start)
 {
     if (!K.reorder) {
-        if (c.s >= K.spp) return false;
-        start = c.st;
-        c.st *= kSampleStride;
-        c.s++;
+        if (c.head >= K.spp) return false;
+        start = c.st_head;
+        c.st_head *= kSampleStride;
+        c.head++;
         return true;
     }
     for (;;) {
-        while (c.s < K.spp) {
-            const uint32_t st = c.st;
-            c.st *= kSampleStride;
-            c.s++;
-            if (roulette_class(K, st) == c.cls) { start = st; return true; }
+        const bool starved = c.pending == 0u;
+        if (starved && c.head >= K.spp && c.cls >= 1) {      /* no more samples of this class: next class */
+            c.cls--;
+            c.head = 0;
+            c.st_head = cursor_first_state(K, *seed_w);
         }
-        if (--c.cls < 1) return false;
-        c.s = 0;
-        c.st = c.st0;
+        const bool done = c.cls < 1;
+        if (__builtin_amdgcn_ballot_w64(starved && !done) == 0) break;
+        if (!done && c.head < K.spp && (c.pending >> 31) == 0u) {
+            c.pending = (c.pending << 1) | (roulette_class(K, c.st_head) == c.cls ? 1u : 0u);
+            c.head++;
+            c.st_head *= kSampleStride;
+        }
     }
+    if (c.cls < 1) return false;
+    const int i = 31 - __builtin_clz(c.pending);             /* oldest pending sample: index head-1-i */
+    c.pending &= ~(1u << i);
+    uint32_t st = c.st_head * stride_inv_pow2(0);
+#pragma unroll
+    for (int j = 0; j < 5; j++) st *= ((i >> j) & 1) ? stride_inv_pow2(j) : 1u;
+    start = st;
+    return true;
 }
 
 /* one link of the per-pixel hit-id chain (the additive constant keeps a run of

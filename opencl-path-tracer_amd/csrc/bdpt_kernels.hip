@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
     pixel_coord(K, x, y, xt, yt);
 
     uint32_t start;
-    for (int s = 0; cursor_next(cur, K, start); s++) {                    /* s counts the samples taken so far */
+    for (int s = 0; cursor_next(cur, K, &K.seed_w[pix], start); s++) {                    /* s counts the samples taken so far */
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
     bool live = inside;                                   /* false once the pixel has no more samples in this launch */
     for (int s = 0;; s++) {                                               /* s counts the samples taken so far */
         uint32_t start = 0;
-        if (live) live = cursor_next(cur, K, start);
+        if (live) live = cursor_next(cur, K, &K.seed_w[pix], start);
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;

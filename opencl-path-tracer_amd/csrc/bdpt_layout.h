@@ -76,10 +76,8 @@ struct bdpt_kargs {
     float falloff_c;
     int accum_mode;
     /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
-     * gives their light subpath (see sample_cursor in bdpt_device.h); fate_mul[k] = 48271^(9+4k)
-     * turns a sample's start state into the state of its k-th roulette draw */
+     * gives their light subpath (see SampleCursor in bdpt_device.h) */
     int reorder;
-    uint32_t fate_mul[8];
 };
 
 #endif

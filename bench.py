@@ -90,7 +90,10 @@ def main():
     else:
         scene, scene_name = bdpt.Scene.soup(args.soup), "Cornell box + %d-triangle soup" % args.soup
     ctx = bdpt.Context(W, H, device=local_rank)
-    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel))
+    # roulette-class order pays where most samples reach the light loop; in the open c3 scene 7 of 8 eye rays leave the scene
+    order = bdpt.ORDER_INDEX if args.workload == "c3" else bdpt.ORDER_ROULETTE_CLASS
+    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel,
+                                       sample_order=order))
     ctx.upload_scene(scene)
     ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED))
     ctx.set_camera(scene.camera)
@@ -145,7 +148,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s, %dx%d, %d spp per GPU per step, exhaustive closest hit" % (scene_name, W, H, SPP),
-            "rng_mode": "strided", "split": "samples per pixel" if world > 1 else "none",
+            "rng_mode": "strided", "accumulate": "sum", "sample_order": "index" if order == bdpt.ORDER_INDEX else "roulette class",
+            "split": "samples per pixel" if world > 1 else "none",
             "combine": "RCCL reduce(sum) of %dx%dx4 f32 to rank 0" % (W, H) if world > 1 else "none",
         },
     }
@@ -169,13 +173,20 @@ def main():
             "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
         }
         out["hbm_gbps_algorithmic"] = round(W * H * 36 / avg_s / 1e9, 3)   # 16 B read + 16 B write + 4 B seed per pixel per launch
+        # the same frame with the reference's sequential generator and running-mean blend (one launch, untimed above):
+        # samples are taken in index order there, so the wavefronts pay for roulette divergence
+        ctx.set_params(bdpt.default_params(kernel_variant=args.kernel))
+        ctx.num_samples = 0
+        ctx.render(SPP)
+        out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
+                              "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_bind as oracle   # the checker, timed here as the CPU baseline
 
         threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-        cw, ch, cspp = min(W, 640), min(H, 360), 64
+        cw, ch, cspp = min(W, 640), min(H, 360), 512
         region = ((W - cw) // 2, (H - ch) // 2, cw, ch)
         st = oracle.State(W, H, bdpt.make_seeds(W, H, 0x5EED))
         p = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)

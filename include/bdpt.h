@@ -75,6 +75,17 @@ enum { BDPT_RNG_STREAM = 0, BDPT_RNG_STRIDED = 1 };
 enum { BDPT_LIGHT_ORIGIN_SELF = 0, BDPT_LIGHT_ORIGIN_NONE = 1 };
 enum { BDPT_FALLOFF_INV_SQ = 0, BDPT_FALLOFF_INV_SQ_PLUS_C = 1 };
 enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
+/* Order in which one launch takes the samples of a pixel.
+ * INDEX:          ascending sample index (the only order STREAM mode and MEAN accumulation allow).
+ * ROULETTE_CLASS: STRIDED + SUM only.  The length Russian roulette gives a sample's light subpath
+ *                 (its class, 1..max_light_bounces) follows from the sample's start state alone; the
+ *                 launch adds the samples of the longest class first, then the next shorter one, ...,
+ *                 ascending sample index within a class.  Every sample is the same as in INDEX order;
+ *                 only the order of the float additions into the accumulator differs.  Wavefronts then
+ *                 trace subpaths of equal length together, which pays when most samples reach the
+ *                 light loop (closed scenes) and costs when most eye rays leave the scene.
+ * AUTO:           ROULETTE_CLASS when it is allowed, else INDEX. */
+enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2 };
 /* Kernel variants; all give identical results.
  * DIRECT: every lane walks the primitive arrays with wave-uniform scalar loads.
  * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
@@ -107,6 +118,7 @@ typedef struct bdpt_params {
     int32_t accum_mode;
     int32_t aov_enable;         /* maintain the bdpt_read_aov() buffers */
     int32_t kernel_variant;     /* BDPT_KERNEL_* */
+    int32_t sample_order;       /* BDPT_ORDER_* */
 } bdpt_params;
 
 typedef struct bdpt_ctx bdpt_ctx;

@@ -117,6 +117,7 @@ void bdpt_default_params(bdpt_params *p)
     p->accum_mode = BDPT_ACCUM_MEAN;
     p->aov_enable = 0;
     p->kernel_variant = BDPT_KERNEL_AUTO;
+    p->sample_order = BDPT_ORDER_AUTO;
 }
 
 int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
@@ -220,6 +221,10 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
     if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_TILED)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
+    if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ROULETTE_CLASS)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
+    if (p->sample_order == BDPT_ORDER_ROULETTE_CLASS && !(p->rng_mode == BDPT_RNG_STRIDED && p->accum_mode == BDPT_ACCUM_SUM))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS needs rng_mode STRIDED and accum_mode SUM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->params = *p;
     if (p->aov_enable) return ensure_aovs(ctx);
@@ -454,7 +459,17 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.falloff = P.connection_falloff;
     K.falloff_c = P.falloff_c;
     K.accum_mode = P.accum_mode;
-    K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM) ? 1 : 0;
+    K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.sample_order != BDPT_ORDER_INDEX) ? 1 : 0;
+    /* (float)x * 2^-32 > p_con, the roulette test of kernel0.cl:788, as an integer test x > fate_above: the
+     * conversion is monotone in x and the scaling exact, so there is one such threshold */
+    {
+        uint64_t lo = 0u, hi = 0xFFFFFFFFu;                               /* largest x whose draw does not exceed p_con */
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1u) / 2u;
+            if ((float)(uint32_t)mid * 0x1p-32f > P.p_continue) hi = mid - 1u; else lo = mid;
+        }
+        K.fate_above = (uint32_t)lo;
+    }
     return BDPT_OK;
 }
 

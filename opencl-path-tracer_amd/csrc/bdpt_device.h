@@ -346,8 +346,7 @@ BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
     int cls = K.max_l;
     uint32_t x = start_state * lcg_pow(9);
     for (int k = 0; k + 1 < K.max_l; k++) {
-        const float fate = (float)x * 0x1p-32f;
-        cls = (fate > K.p_con && cls == K.max_l) ? k + 1 : cls;                      /* :788 */
+        cls = (x > K.fate_above && cls == K.max_l) ? k + 1 : cls;                    /* :788 */
         x *= lcg_pow(4);
     }
     return cls;

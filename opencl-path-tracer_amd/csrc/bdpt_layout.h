@@ -78,6 +78,7 @@ struct bdpt_kargs {
     /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
      * gives their light subpath (see SampleCursor in bdpt_device.h) */
     int reorder;
+    uint32_t fate_above;        /* a roulette draw x ends the subpath iff x > fate_above */
 };
 
 #endif

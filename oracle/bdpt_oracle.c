@@ -470,7 +470,8 @@ static void render_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt
 
     /* A STRIDED + SUM call adds its samples class by class (longest roulette class first, sample
      * index ascending within a class); every other combination takes them in index order. */
-    const int reorder = P->rng_mode == BDPT_RNG_STRIDED && P->accum_mode == BDPT_ACCUM_SUM;
+    const int reorder = P->rng_mode == BDPT_RNG_STRIDED && P->accum_mode == BDPT_ACCUM_SUM &&
+                        P->sample_order != BDPT_ORDER_INDEX;
     const uint32_t stride = pow_u32(48271u, 32u);
     int taken = 0;
     for (int cls = reorder ? P->max_light_bounces : 1; cls >= 1; cls--)

@@ -240,6 +240,37 @@ def test_strided_sum_launch_adds_by_roulette_class(bdpt, oracle, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("p_continue,max_l", [(0.8, 5), (0.5, 7), (0.93, 3), (0.8, 1)])
+def test_sample_orders_take_the_same_samples(bdpt, oracle, variant, p_continue, max_l):
+    """STRIDED + SUM with sample_order INDEX and ROULETTE_CLASS: each bit-exact against the oracle in its own order,
+    the same draw and ray counts in both (every sample is taken exactly once), sums equal to rounding."""
+    scene = bdpt.Scene.cornell()
+    W, H, SPP = 40, 24, 70          # 70 samples: more than two 32-sample look-ahead windows
+    res = {}
+    for order in (bdpt.ORDER_INDEX, bdpt.ORDER_ROULETTE_CLASS):
+        ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=23, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM,
+                           kernel_variant=variant, sample_order=order, p_continue=p_continue, max_light_bounces=max_l)
+        ctx.render(SPP)
+        oracle.render(st, scene, scene.camera, p, SPP, n_threads=8)
+        _compare(bdpt, ctx, st, "order %d:" % order)
+        res[order] = (ctx.read_accum(), ctx.read_aov(bdpt.AOV_RNG_DRAWS), ctx.read_aov(bdpt.AOV_RAYS))
+        ctx.close()
+    a, b = res[bdpt.ORDER_INDEX], res[bdpt.ORDER_ROULETTE_CLASS]
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-5, atol=1e-5)
+
+
+def test_roulette_class_order_needs_strided_sum(bdpt):
+    ctx = bdpt.Context(16, 16)
+    for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):
+        with pytest.raises(bdpt.BdptError, match="sample_order"):
+            ctx.set_params(bdpt.default_params(sample_order=bdpt.ORDER_ROULETTE_CLASS, **kw))
+    ctx.set_params(bdpt.default_params(sample_order=bdpt.ORDER_ROULETTE_CLASS, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM))
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_region_renders_only_its_pixels(bdpt, oracle, variant):
     scene = bdpt.Scene.cornell()
     W, H = 64, 64

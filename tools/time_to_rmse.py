@@ -67,7 +67,12 @@ ctx, part = make_ctx(0x5EED, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SU
 ctx.render(1)                      # warm-up: code object load and first-touch are not part of the measurement
 ctx.set_camera(scene.camera)       # the reset the clock starts at
 total = torch.zeros_like(part)
+if rank == 0:                      # the same for the device code of the RMSE evaluation
+    total += part
+    torch.sqrt(torch.mean(((total[..., :3] / 1).clamp(0, 1) - ref) ** 2)).item()
+    total.zero_()
 if world > 1:
+    dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)
     dist.barrier()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -57,6 +57,8 @@ def main():
                          "--width/--height are given; c4: Cornell box + 100k-triangle soup")
     ap.add_argument("--soup", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-line", action="store_true",
+                    help="also time one launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,11 +177,12 @@ def main():
         out["hbm_gbps_algorithmic"] = round(W * H * 36 / avg_s / 1e9, 3)   # 16 B read + 16 B write + 4 B seed per pixel per launch
         # the same frame with the reference's sequential generator and running-mean blend (one launch, untimed above):
         # samples are taken in index order there, so the wavefronts pay for roulette divergence
-        ctx.set_params(bdpt.default_params(kernel_variant=args.kernel))
-        ctx.num_samples = 0
-        ctx.render(SPP)
-        out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
-                              "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2)}
+        if args.stream_line:
+            ctx.set_params(bdpt.default_params(kernel_variant=args.kernel))
+            ctx.num_samples = 0
+            ctx.render(SPP)
+            out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
+                                  "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

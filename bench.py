@@ -57,6 +57,8 @@ def main():
                          "--width/--height are given; c4: Cornell box + 100k-triangle soup")
     ap.add_argument("--soup", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1; gloo only to rehearse the N > 1 code path with several ranks on one GPU")
     ap.add_argument("--stream-line", action="store_true",
                     help="also time one launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
     args = ap.parse_args()
@@ -74,9 +76,14 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the path tracer has no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import numpy as np
 
@@ -109,8 +116,13 @@ def main():
     def step(record):
         ctx.num_samples = 0                 # a fresh image each step; the first sample overwrites the accumulator
         ctx.render_async(SPP)
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        elif world > 1:                     # rehearsal: gloo reduces host tensors
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                accum.copy_(host)
         if record:
             launch_ms.append(ctx.last_launch_ms())
 
@@ -129,7 +141,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

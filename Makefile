@@ -20,7 +20,7 @@ LIB_SRCS := $(CSRC)/bdpt_api.cpp $(CSRC)/bdpt_kernels.hip
 LIB_DEPS := $(LIB_SRCS) $(wildcard $(CSRC)/*.h) include/bdpt.h include/bdpt_clmath.h
 
 HOSTLIB  := $(PKG)/libbdpt_host.so
-HOST_SRCS := $(PKG)/host/camera.cpp $(PKG)/host/scenes.cpp $(PKG)/host/renderer.cpp $(PKG)/host/capi.cpp
+HOST_SRCS := $(PKG)/host/camera.cpp $(PKG)/host/scenes.cpp $(PKG)/host/renderer.cpp $(PKG)/host/scene_io.cpp $(PKG)/host/image_io.cpp $(PKG)/host/capi.cpp
 HOST_DEPS := $(HOST_SRCS) $(PKG)/host/bdpt_host.h include/bdpt.h
 CXX      ?= g++
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall

@@ -120,6 +120,13 @@ hostlib.bdpt_host_camera_orbit.restype = None
 hostlib.bdpt_host_make_seeds.argtypes = [C.c_int, C.c_int, C.c_uint32, _vp]
 hostlib.bdpt_host_make_seeds.restype = None
 hostlib.bdpt_host_write_pfm.argtypes = [C.c_char_p, _vp, C.c_int, C.c_int]
+hostlib.bdpt_host_scene_load.restype = _vp
+hostlib.bdpt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+hostlib.bdpt_host_scene_save.argtypes = [_vp, C.c_char_p, C.c_int]
+hostlib.bdpt_host_scene_add_obj.argtypes = [_vp, C.c_char_p, C.c_uint32, C.c_float, _vp, C.c_char_p, C.c_int]
+hostlib.bdpt_host_scene_view.argtypes = [_vp, _vp]
+hostlib.bdpt_host_scene_view.restype = None
+hostlib.bdpt_host_write_image.argtypes = [C.c_char_p, _vp, C.c_int, C.c_int, C.c_float, C.c_float]
 
 
 def version():
@@ -160,6 +167,51 @@ class Scene:
         h = hostlib.bdpt_host_scene_create(kind, n_soup, seed)
         if not h:
             raise ValueError("unknown scene kind %r" % (kind,))
+        return Scene._take(h)
+
+    @staticmethod
+    def load(path, objs=()):
+        """Scene file (text or binary, see host/scene_io.cpp), then OBJ files appended as triangles:
+        objs = [(path, surface, scale, (tx, ty, tz)), ...]."""
+        err = C.create_string_buffer(512)
+        h = hostlib.bdpt_host_scene_load(os.fsencode(path), err, len(err))
+        if not h:
+            raise ValueError(err.value.decode())
+        for obj_path, surface, scale, translate in objs:
+            tr = np.asarray(translate, np.float32)
+            if hostlib.bdpt_host_scene_add_obj(h, os.fsencode(obj_path), surface, scale, _ptr(tr), err, len(err)) < 0:
+                hostlib.bdpt_host_scene_destroy(h)
+                raise ValueError(err.value.decode())
+        return Scene._take(h)
+
+    def save(self, path, binary=False):
+        """Writes the scene through the C++ host (round-trips through Scene.load)."""
+        import tempfile
+        # hand the arrays to the host library as a binary scene file, then let it write the requested form
+        hdr = np.zeros((), np.dtype([("magic", "S8"), ("n", "<u4", 4), ("view", "<f4", 4)]))
+        hdr["magic"] = b"BDPTSCN1"
+        hdr["n"] = [len(self.spheres), len(self.planes), len(self.triangles), len(self.surfaces)]
+        hdr["view"] = getattr(self, "view", (1.0, 0.1, -0.1, 8.0))
+        blob = hdr.tobytes() + self.spheres.tobytes() + self.planes.tobytes() + self.triangles.tobytes() + self.surfaces.tobytes()
+        if binary:
+            with open(path, "wb") as f:
+                f.write(blob)
+            return
+        with tempfile.NamedTemporaryFile(suffix=".bdptscn") as tmp:
+            tmp.write(blob)
+            tmp.flush()
+            err = C.create_string_buffer(512)
+            h = hostlib.bdpt_host_scene_load(os.fsencode(tmp.name), err, len(err))
+            if not h:
+                raise ValueError(err.value.decode())
+            try:
+                if hostlib.bdpt_host_scene_save(h, os.fsencode(path), 0) != 0:
+                    raise OSError("cannot write %s" % path)
+            finally:
+                hostlib.bdpt_host_scene_destroy(h)
+
+    @staticmethod
+    def _take(h):
         try:
             cnt = (C.c_int * 4)()
             hostlib.bdpt_host_scene_counts(h, cnt)
@@ -173,8 +225,12 @@ class Scene:
 
             cam = np.zeros((), camera_dtype)
             hostlib.bdpt_host_scene_default_camera(h, cam.ctypes.data_as(_vp))
-            return Scene(grab("spheres", sphere_dtype, cnt[0]), grab("planes", plane_dtype, cnt[1]),
-                         grab("triangles", triangle_dtype, cnt[2]), grab("surfaces", surface_dtype, cnt[3]), cam)
+            view = (C.c_float * 4)()
+            hostlib.bdpt_host_scene_view(h, view)
+            sc = Scene(grab("spheres", sphere_dtype, cnt[0]), grab("planes", plane_dtype, cnt[1]),
+                       grab("triangles", triangle_dtype, cnt[2]), grab("surfaces", surface_dtype, cnt[3]), cam)
+            sc.view = tuple(view)
+            return sc
         finally:
             hostlib.bdpt_host_scene_destroy(h)
 
@@ -223,6 +279,14 @@ def write_pfm(path, rgba):
     rgba = _as(rgba, np.float32)
     h, w = rgba.shape[:2]
     if hostlib.bdpt_host_write_pfm(os.fsencode(path), _ptr(rgba), w, h) != 0:
+        raise OSError("cannot write %s" % path)
+
+
+def write_image(path, rgba, scale=1.0, gamma=1.0):
+    """.pfm (float), .ppm or .png (8-bit: clamp(v*scale, 0, 1) ** (1/gamma))."""
+    rgba = _as(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    if hostlib.bdpt_host_write_image(os.fsencode(path), _ptr(rgba), w, h, scale, gamma) != 0:
         raise OSError("cannot write %s" % path)
 
 

@@ -10,6 +10,8 @@
  *   renderer/main.cpp:270-422      -> cornell_scene (the hard-coded scene)
  *   renderer/main.cpp:100-172      -> Renderer::frame (mainLoop)
  *   renderer/main.cpp:456-460      -> make_seeds (deterministic instead of rand())
+ *   geometry/loader.cpp:8-85       -> load_obj (+ append_mesh: OBJ faces as tracer triangles)
+ *   renderer/main.cpp:140-145      -> write_image (PFM / PPM / PNG instead of the present blit)
  */
 #ifndef BDPT_HOST_H
 #define BDPT_HOST_H
@@ -122,8 +124,34 @@ private:
     ModelCamera cam;
 };
 
-/* N3: writes a little-endian PFM (RGB, bottom row first) of an RGBA float image */
+/* ---- scene input from files (scene_io.cpp) ---- */
+
+/* what ModelLoader::load keeps of an OBJ file that matters to the tracer */
+struct ObjMesh {
+    std::vector<vec3> positions;
+    std::vector<uint32_t> indices;      /* 3 per triangle, 0-based into positions, file order and winding */
+    size_t n_uvs = 0, n_normals = 0;    /* `vt` / `vn` records seen (the tracer has no use for their values) */
+};
+bool load_obj(const std::string &path, ObjMesh &mesh, std::string *err = nullptr);
+/* adds the mesh's faces as triangles of `surface`, each vertex scaled then translated; returns the number added */
+size_t append_mesh(Scene &scene, const ObjMesh &mesh, uint32_t surface, float scale = 1.0f, vec3 translate = {0.f, 0.f, 0.f});
+bool validate_scene(const Scene &scene, std::string *err, const std::string &what);
+bool load_scene_text(const std::string &path, Scene &scene, std::string *err = nullptr);
+bool save_scene_text(const std::string &path, const Scene &scene);
+bool load_scene_binary(const std::string &path, Scene &scene, std::string *err = nullptr);
+bool save_scene_binary(const std::string &path, const Scene &scene);
+bool load_scene(const std::string &path, Scene &scene, std::string *err = nullptr);   /* binary or text, by its first bytes */
+
+/* ---- image output (renderer.cpp, image_io.cpp) ---- */
+
+/* little-endian PFM (RGB, bottom row first) of an RGBA float image */
 bool write_pfm(const std::string &path, const float *rgba, int width, int height);
+/* 8-bit RGB: clamp(v * scale, 0, 1) ^ (1 / gamma), rounded to 0..255, top row first */
+std::vector<uint8_t> to_rgb8(const float *rgba, int width, int height, float scale = 1.0f, float gamma = 1.0f);
+bool write_ppm(const std::string &path, const float *rgba, int width, int height, float scale = 1.0f, float gamma = 1.0f);
+bool write_png(const std::string &path, const float *rgba, int width, int height, float scale = 1.0f, float gamma = 1.0f);
+/* by extension: .pfm, .ppm, .png */
+bool write_image(const std::string &path, const float *rgba, int width, int height, float scale = 1.0f, float gamma = 1.0f);
 
 }  // namespace bdpt_host
 
@@ -148,6 +176,15 @@ void bdpt_host_camera_orbit(float radius, const float orientation[3], const floa
                             double dx, double dy, int steps, bdpt_camera *out, int *changed);
 void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t *out);
 int bdpt_host_write_pfm(const char *path, const float *rgba, int width, int height);
+/* scene files: NULL on failure, with the reason in err (if err_len > 0) */
+bdpt_host_scene *bdpt_host_scene_load(const char *path, char *err, int err_len);
+int bdpt_host_scene_save(const bdpt_host_scene *s, const char *path, int binary);
+void bdpt_host_scene_view(const bdpt_host_scene *s, float dir_radius[4]);
+/* appends the faces of an OBJ file as triangles; returns how many, or -1 with the reason in err */
+int bdpt_host_scene_add_obj(bdpt_host_scene *s, const char *path, uint32_t surface, float scale, const float translate[3],
+                            char *err, int err_len);
+/* by extension (.pfm / .ppm / .png); 0 on success */
+int bdpt_host_write_image(const char *path, const float *rgba, int width, int height, float scale, float gamma);
 }
 
 #endif

@@ -2,6 +2,9 @@
  * capi.cpp -- C-ABI over the host-side scene, camera and seed helpers, for
  * bindings that cannot call C++ (the Python tests and the benchmark driver).
  */
+#include <cstdio>
+#include <string>
+
 #include "bdpt_host.h"
 
 using namespace bdpt_host;
@@ -84,6 +87,52 @@ void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t 
 int bdpt_host_write_pfm(const char *path, const float *rgba, int width, int height)
 {
     return write_pfm(path, rgba, width, height) ? 0 : -1;
+}
+
+static void put_err(char *err, int err_len, const std::string &what)
+{
+    if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", what.c_str());
+}
+
+bdpt_host_scene *bdpt_host_scene_load(const char *path, char *err, int err_len)
+{
+    bdpt_host_scene *s = new bdpt_host_scene();
+    std::string what;
+    if (!path || !load_scene(path, s->sc, &what)) {
+        put_err(err, err_len, path ? what : "null path");
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+int bdpt_host_scene_save(const bdpt_host_scene *s, const char *path, int binary)
+{
+    if (!s || !path) return -1;
+    return (binary ? save_scene_binary(path, s->sc) : save_scene_text(path, s->sc)) ? 0 : -1;
+}
+
+void bdpt_host_scene_view(const bdpt_host_scene *s, float dir_radius[4])
+{
+    dir_radius[0] = s->sc.view_dir.x; dir_radius[1] = s->sc.view_dir.y; dir_radius[2] = s->sc.view_dir.z;
+    dir_radius[3] = s->sc.view_radius;
+}
+
+int bdpt_host_scene_add_obj(bdpt_host_scene *s, const char *path, uint32_t surface, float scale, const float translate[3],
+                            char *err, int err_len)
+{
+    if (!s || !path) { put_err(err, err_len, "null argument"); return -1; }
+    if (surface >= s->sc.surfaces.size()) { put_err(err, err_len, "surface does not exist"); return -1; }
+    ObjMesh mesh;
+    std::string what;
+    if (!load_obj(path, mesh, &what)) { put_err(err, err_len, what); return -1; }
+    const vec3 tr = translate ? vec3{translate[0], translate[1], translate[2]} : vec3{0.f, 0.f, 0.f};
+    return (int)append_mesh(s->sc, mesh, surface, scale, tr);
+}
+
+int bdpt_host_write_image(const char *path, const float *rgba, int width, int height, float scale, float gamma)
+{
+    return (path && rgba && write_image(path, rgba, width, height, scale, gamma)) ? 0 : -1;
 }
 
 }  /* extern "C" */

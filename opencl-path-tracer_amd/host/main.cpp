@@ -5,9 +5,10 @@
  * instead of until the window closes, and write the image instead of
  * presenting it.
  *
- *   bdpt_host [--scene cornell|planes|outdoor|soup] [--soup N] [--width W]
- *             [--height H] [--frames F] [--spp S] [--orbit-frames K]
- *             [--seed G] [--device D] [--out image.pfm] [--quiet]
+ *   bdpt_host [--scene cornell|planes|outdoor|soup] [--soup N] [--scene-file F]
+ *             [--obj model.obj [--obj-surface I] [--obj-scale S] [--obj-translate X,Y,Z]]
+ *             [--width W] [--height H] [--frames F] [--spp S] [--orbit-frames K]
+ *             [--seed G] [--device D] [--out image.pfm|.ppm|.png [--gamma G]] [--quiet]
  */
 #include <chrono>
 #include <cstdio>
@@ -21,7 +22,10 @@ using namespace bdpt_host;
 
 int main(int argc, char **argv)
 {
-    std::string scene_name = "cornell", out_path;
+    std::string scene_name = "cornell", out_path, scene_file, obj_path;
+    int obj_surface = 0;
+    float obj_scale = 1.0f, gamma = 1.0f;
+    vec3 obj_translate{0.f, 0.f, 0.f};
     int width = 1067, height = 600;                                       /* main.cpp:35-36 */
     int frames = 64, spp = 1, orbit_frames = 0, n_soup = 100000, device = 0;
     uint32_t seed = 0x5EEDu;
@@ -41,16 +45,42 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--seed")) seed = (uint32_t)std::strtoul(next("--seed"), nullptr, 0);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next("--device"));
         else if (!std::strcmp(argv[i], "--out")) out_path = next("--out");
+        else if (!std::strcmp(argv[i], "--gamma")) gamma = (float)std::atof(next("--gamma"));
+        else if (!std::strcmp(argv[i], "--scene-file")) scene_file = next("--scene-file");
+        else if (!std::strcmp(argv[i], "--obj")) obj_path = next("--obj");
+        else if (!std::strcmp(argv[i], "--obj-surface")) obj_surface = std::atoi(next("--obj-surface"));
+        else if (!std::strcmp(argv[i], "--obj-scale")) obj_scale = (float)std::atof(next("--obj-scale"));
+        else if (!std::strcmp(argv[i], "--obj-translate")) {
+            if (std::sscanf(next("--obj-translate"), "%f,%f,%f", &obj_translate.x, &obj_translate.y, &obj_translate.z) != 3) {
+                std::fprintf(stderr, "ERROR: --obj-translate needs X,Y,Z\n");
+                return EXIT_FAILURE;
+            }
+        }
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else { std::fprintf(stderr, "ERROR: unknown argument %s\n", argv[i]); return EXIT_FAILURE; }
     }
 
     Scene scene;
-    if (scene_name == "cornell") scene = cornell_scene();
+    std::string why;
+    if (!scene_file.empty()) {
+        if (!load_scene(scene_file, scene, &why)) { std::fprintf(stderr, "ERROR: %s\n", why.c_str()); return EXIT_FAILURE; }
+    }
+    else if (scene_name == "cornell") scene = cornell_scene();
     else if (scene_name == "planes") scene = cornell_planes_scene();
     else if (scene_name == "outdoor") scene = outdoor_scene();
     else if (scene_name == "soup") scene = soup_scene(n_soup);
     else { std::fprintf(stderr, "ERROR: unknown scene %s\n", scene_name.c_str()); return EXIT_FAILURE; }
+
+    if (!obj_path.empty()) {
+        ObjMesh mesh;
+        if (!load_obj(obj_path, mesh, &why)) { std::fprintf(stderr, "ERROR: %s\n", why.c_str()); return EXIT_FAILURE; }
+        if (obj_surface < 0 || (size_t)obj_surface >= scene.surfaces.size()) {
+            std::fprintf(stderr, "ERROR: --obj-surface %d does not exist\n", obj_surface);
+            return EXIT_FAILURE;
+        }
+        const size_t n = append_mesh(scene, mesh, (uint32_t)obj_surface, obj_scale, obj_translate);
+        std::printf("%s: %zu vertices, %zu triangles\n", obj_path.c_str(), mesh.positions.size(), n);   /* loader.cpp:83 */
+    }
 
     Renderer r(device, width, height);
     r.verbose = !quiet;
@@ -73,7 +103,7 @@ int main(int argc, char **argv)
 
     if (!out_path.empty()) {
         std::vector<float> img = r.readImage();
-        if (!write_pfm(out_path, img.data(), width, height)) {
+        if (!write_image(out_path, img.data(), width, height, 1.0f, gamma)) {
             std::fprintf(stderr, "ERROR: cannot write %s\n", out_path.c_str());
             return EXIT_FAILURE;
         }

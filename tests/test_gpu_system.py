@@ -156,3 +156,33 @@ def test_host_binary_loads_a_scene_file_and_writes_a_png(bdpt, tmp_path):
     assert raw[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(raw[16:20], "big") == 160 and int.from_bytes(raw[20:24], "big") == 90
     bad = subprocess.run([exe, "--scene-file", str(tmp_path / "missing.scn")], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "cannot open" in bad.stderr
+
+
+def test_c1_configuration_frame_loop_matches_the_oracle_at_full_size(bdpt):
+    """Cornell box 512x512, 64 frames of one sample with the sample counter 0..63 (the reference's frame loop,
+    main.cpp:108-131): accumulator, generator state and hit-id chains of the whole frame, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_bind as oracle
+
+    W = H = 512
+    FRAMES = 64
+    scene = bdpt.Scene.cornell()
+    seeds = bdpt.make_seeds(W, H, 0x5EED)
+    p = bdpt.default_params(aov_enable=1)
+    with bdpt.Context(W, H) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(seeds)
+        ctx.set_camera(scene.camera)
+        for _ in range(FRAMES):
+            ctx.render(1)
+        assert ctx.num_samples == FRAMES
+        acc, hsh, out_seeds = ctx.read_accum(), ctx.read_aov(bdpt.AOV_HIT_HASH), ctx.read_seeds()
+    st = oracle.State(W, H, seeds)
+    for _ in range(FRAMES):
+        oracle.render(st, scene, scene.camera, p, 1, n_threads=16)
+    assert np.array_equal(hsh, st.hit_hash)
+    assert np.array_equal(out_seeds, st.seeds)
+    assert np.array_equal(acc.view(np.uint32), st.accum.view(np.uint32))
+    assert 0.15 < acc[..., :3].mean() < 0.45

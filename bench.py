@@ -132,6 +132,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up that is not a step: load the code object and, for N > 1, build the communicator (both happen on first use)
+    ctx.render(1)
+    if world > 1:
+        probe = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
     for _ in range(args.warmup):
         step(False)
     fence()

@@ -4,9 +4,9 @@ seeded inputs.  Bars (stated once, used below):
     counts: bit-exact;
   - per-sample radiance and accumulated image: the arithmetic is specified
     operation by operation (include/bdpt_clmath.h), so these are compared
-    bit-exact as well; RADIANCE_RTOL/ATOL is the documented fallback bar of the
-    north star (fp32 relative 1e-5, absolute 1e-7) and is asserted first so a
-    failure says how far off the values are.
+    bit-exact as well; RADIANCE_RTOL/ATOL is the stated floating-point bar
+    (fp32 relative 1e-5, absolute 1e-7) and is asserted first so a failure says
+    how far off the values are.
 """
 import numpy as np
 import pytest

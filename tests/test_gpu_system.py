@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RMSE_BOUND = 0.02      # on linear RGB clamped to [0,1]; the north star's converged-image bar
+RMSE_BOUND = 0.02      # on linear RGB clamped to [0,1]: the converged-image bar
 
 
 def _rmse(a, b):

@@ -60,7 +60,8 @@ class BdptError(RuntimeError):
 
 
 def _load(name):
-    path = os.path.join(_HERE, name)
+    # BDPT_LIB_DIR: directory of an alternative build of the libraries (A/B timing of two builds in one GPU session)
+    path = os.path.join(os.environ.get("BDPT_LIB_DIR", _HERE), name)
     if not os.path.exists(path):
         raise ImportError("%s is not built; run `make` (or __graft_entry__.build()) at the repository root" % path)
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

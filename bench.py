@@ -30,17 +30,17 @@ F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flo
 F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
 
 
-def hbm_traffic_bytes(width, height):
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled as the
-    gfx950 correction for wide coalesced reads, plus WRITE_SIZE; both are independent of spp), or None when no pass
-    was recorded for this image size."""
+def hbm_traffic_bytes(workload, width, height, spp):
+    """HBM-side bytes per launch of the render kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
+    gfx950 correction for wide coalesced reads, plus WRITE_SIZE), or None when no pass was recorded for this workload
+    and image size."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            rec = json.load(f)
+            rec = json.load(f).get("%s/%dx%d" % (workload, width, height))
     except (OSError, ValueError):
         return None
-    return rec.get("%dx%d" % (width, height), {}).get("bytes_per_launch")
+    return None if rec is None else rec["fixed"] + rec["per_spp"] * spp
 
 
 def main():
@@ -187,7 +187,7 @@ def main():
         achieved = flops / avg_s / 1e12
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": hbm_traffic_bytes(W, H),
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": hbm_traffic_bytes(args.workload, W, H, SPP),
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
             "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
         }

@@ -104,7 +104,10 @@ typedef struct bdpt_params {
     /* BDPT_RNG_STREAM: the reference's sequential per-pixel LCG, including its
      * behaviour on early-out samples (no seed write-back, raw value written).
      * BDPT_RNG_STRIDED: sample s of a pixel starts at seed * 48271^(32*s), so
-     * any rank can render any sample range; early-outs are ordinary samples. */
+     * any rank can render any sample range; early-outs are ordinary samples.
+     * A sample draws 5 + 4 per light-subpath vertex numbers, the first of them
+     * discarded (kernel0.cl:592): no number is used by two samples while
+     * max_light_bounces <= 7. */
     int32_t rng_mode;
     /* Which primitive the first light-subpath rays skip.  The reference reads
      * an uninitialised id here (kernel0.cl:547-569, :675, :705); SELF = the

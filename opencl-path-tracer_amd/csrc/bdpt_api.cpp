@@ -194,11 +194,16 @@ static int ensure_aovs(bdpt_ctx *ctx)
 {
     if (ctx->d_aov_hash) return BDPT_OK;
     const size_t npix = (size_t)ctx->width * ctx->height;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_eye, npix * 2 * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_draws, npix * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_rays, npix * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_rad, npix * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_aov_hash, npix * sizeof(uint32_t)));
+    hipError_t e = hipMalloc((void **)&ctx->d_aov_eye, npix * 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_aov_draws, npix * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_aov_rays, npix * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_aov_rad, npix * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_aov_hash, npix * sizeof(uint32_t));   /* last: its presence means "all five exist" */
+    if (e != hipSuccess) {
+        dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays); dev_free(ctx->d_aov_rad);
+        dev_free(ctx->d_aov_hash);
+        return fail(ctx, BDPT_ERR_HIP, std::string("AOV buffers: hipMalloc: ") + hipGetErrorString(e));
+    }
     return reset_aovs(ctx);
 }
 
@@ -482,13 +487,13 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool aov = ctx->params.aov_enable != 0;
     if (aov && (rc = ensure_aovs(ctx)) != BDPT_OK) return rc;
-    if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     int variant = ctx->params.kernel_variant;
     if (variant == BDPT_KERNEL_LDS && bdpt_lds_scene_bytes(K.scene) > BDPT_LDS_SCENE_MAX)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
     /* AUTO: keep the scene in LDS when it fits, otherwise stage it through LDS tiles */
     if (variant == BDPT_KERNEL_AUTO) variant = bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
+    if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));

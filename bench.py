@@ -43,6 +43,31 @@ def hbm_traffic_bytes(workload, width, height, spp):
     return None if rec is None else rec["fixed"] + rec["per_spp"] * spp
 
 
+def cpu_opencl_status():
+    """Whether the reference's OpenCL kernel could be timed on this host: it needs a CPU OpenCL device (PoCL or the
+    like).  Returns a short reason string; this build has no harness for that route because no image it was developed
+    on has such a device."""
+    import ctypes
+    try:
+        cl = ctypes.CDLL("libOpenCL.so.1")
+    except OSError:
+        return "unavailable: no OpenCL loader on this host"
+    n = ctypes.c_uint(0)
+    if cl.clGetPlatformIDs(0, None, ctypes.byref(n)) != 0 or n.value == 0:
+        return "unavailable: no OpenCL platform"
+    plats = (ctypes.c_void_p * n.value)()
+    cl.clGetPlatformIDs(n.value, plats, None)
+    CL_DEVICE_TYPE_CPU = 1 << 1
+    cpus = 0
+    for p in plats:
+        m = ctypes.c_uint(0)
+        if cl.clGetDeviceIDs(ctypes.c_void_p(p), ctypes.c_ulong(CL_DEVICE_TYPE_CPU), 0, None, ctypes.byref(m)) == 0:
+            cpus += m.value
+    if cpus == 0:
+        return "unavailable: %d OpenCL platform(s), none with a CPU device" % n.value
+    return "not run: a CPU OpenCL device exists but this build has no harness for the reference kernel"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +241,7 @@ def main():
         out["cpu_baseline"] = {
             "value": round(cw * ch * cspp / cpu_s / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
             "sample": "centre %dx%d crop of the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s" % (cw, ch, W, H, cspp, cpu_s),
+            "reference_opencl_on_cpu": cpu_opencl_status(),
         }
 
     if rank == 0:

@@ -174,6 +174,10 @@ int bdpt_set_num_samples(bdpt_ctx *ctx, int n);
 /* Read-back of the accumulated image, width*height RGBA float, row-major
  * (stands in for the present blit, main.cpp:140-145). */
 int bdpt_read_accum(bdpt_ctx *ctx, float *rgba);
+/* The reverse: replaces the accumulated image (the reference keeps it only in a GL texture and
+ * cannot do this).  With bdpt_read_seeds / bdpt_upload_seeds and bdpt_set_num_samples it lets a
+ * host stop a progressive render and resume it later with identical results. */
+int bdpt_write_accum(bdpt_ctx *ctx, const float *rgba);
 
 /* ---- additions with no reference counterpart ----------------------------- */
 

@@ -91,6 +91,7 @@ lib.bdpt_sync.argtypes = [_vp]
 lib.bdpt_num_samples.argtypes = [_vp]
 lib.bdpt_set_num_samples.argtypes = [_vp, C.c_int]
 lib.bdpt_read_accum.argtypes = [_vp, _vp]
+lib.bdpt_write_accum.argtypes = [_vp, _vp]
 lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
@@ -345,6 +346,12 @@ class Context:
         if seeds.size != self.width * self.height * 4:
             raise ValueError("seeds must hold width*height*4 words")
         self._check(lib.bdpt_upload_seeds(self._h, _ptr(seeds)))
+
+    def write_accum(self, rgba):
+        rgba = _as(rgba, np.float32)
+        if rgba.shape != (self.height, self.width, 4):
+            raise ValueError("accumulator must be height x width x 4")
+        self._check(lib.bdpt_write_accum(self._h, _ptr(rgba)))
 
     def read_seeds(self):
         out = np.empty(self.width * self.height * 4, np.uint32)

@@ -538,6 +538,15 @@ int bdpt_read_accum(bdpt_ctx *ctx, float *rgba)
     return BDPT_OK;
 }
 
+int bdpt_write_accum(bdpt_ctx *ctx, const float *rgba)
+{
+    if (!ctx || !rgba) return fail(ctx, BDPT_ERR_INVALID, "bdpt_write_accum: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_accum, rgba, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyHostToDevice));
+    return BDPT_OK;
+}
+
 int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out)
 {
     if (!ctx || !out) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_aov: null argument");

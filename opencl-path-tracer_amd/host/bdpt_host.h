@@ -72,6 +72,7 @@ public:
     void setScrollSpeed(float s) { fScrollSpeed = s; }
     void setOrientation(vec3 v) { vOrientation = v; }
     void reset(vec3 vDir);                       /* camera.cpp:44-53 */
+    void setPose(const bdpt_camera &c);          /* restores eye, look direction and up from a CLCamera */
     vec3 getEye() const { return vPos; }
     vec3 getLookAt() const { return vLookAt; }
     int isChanged() const { return iState == CAM_ACTIVE; }   /* camera.cpp:62-65: held, not moved */
@@ -111,6 +112,12 @@ public:
     void frame(const InputFrame &in, int spp = 1);
     int numSamples() const;
     std::vector<float> readImage();              /* width*height*4 floats */
+    /* Progressive state to a file and back: image size, sample counter, camera pose, accumulator and
+     * generator state.  A render resumed from a checkpoint continues bit for bit as if it had never
+     * stopped (same scene and parameters assumed).  The reference cannot do this: its accumulator lives
+     * in a GL texture and its seeds are re-drawn at every start (main.cpp:456-460). */
+    bool saveCheckpoint(const std::string &path);
+    bool loadCheckpoint(const std::string &path, std::string *err = nullptr);
     float lastLaunchMs();
     bdpt_ctx *ctx() { return c; }
     int width() const { return w; }

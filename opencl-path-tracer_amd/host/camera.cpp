@@ -64,6 +64,14 @@ void ModelCamera::handleCursor(bool left_down, bool middle_down, double dx, doub
     vUp = normalize(cross(vLookAt, cross(vLookAt, vOrientation)));       /* :130 */
 }
 
+void ModelCamera::setPose(const bdpt_camera &c)
+{
+    vPos = {c.pos[0], c.pos[1], c.pos[2]};
+    vLookAt = {c.look_at[0], c.look_at[1], c.look_at[2]};
+    vUp = {c.up[0], c.up[1], c.up[2]};
+    fRadius = std::sqrt(vPos.x * vPos.x + vPos.y * vPos.y + vPos.z * vPos.z);
+}
+
 bdpt_camera ModelCamera::getCLCamera() const
 {
     bdpt_camera c;

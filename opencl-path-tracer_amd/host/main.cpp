@@ -9,6 +9,7 @@
  *             [--obj model.obj [--obj-surface I] [--obj-scale S] [--obj-translate X,Y,Z]]
  *             [--width W] [--height H] [--frames F] [--spp S] [--orbit-frames K]
  *             [--seed G] [--device D] [--out image.pfm|.ppm|.png [--gamma G]] [--quiet]
+ *             [--resume state.ckpt] [--checkpoint state.ckpt]
  */
 #include <chrono>
 #include <cstdio>
@@ -22,7 +23,7 @@ using namespace bdpt_host;
 
 int main(int argc, char **argv)
 {
-    std::string scene_name = "cornell", out_path, scene_file, obj_path;
+    std::string scene_name = "cornell", out_path, scene_file, obj_path, resume_path, checkpoint_path;
     int obj_surface = 0;
     float obj_scale = 1.0f, gamma = 1.0f;
     vec3 obj_translate{0.f, 0.f, 0.f};
@@ -45,6 +46,8 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--seed")) seed = (uint32_t)std::strtoul(next("--seed"), nullptr, 0);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next("--device"));
         else if (!std::strcmp(argv[i], "--out")) out_path = next("--out");
+        else if (!std::strcmp(argv[i], "--resume")) resume_path = next("--resume");
+        else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint_path = next("--checkpoint");
         else if (!std::strcmp(argv[i], "--gamma")) gamma = (float)std::atof(next("--gamma"));
         else if (!std::strcmp(argv[i], "--scene-file")) scene_file = next("--scene-file");
         else if (!std::strcmp(argv[i], "--obj")) obj_path = next("--obj");
@@ -86,6 +89,10 @@ int main(int argc, char **argv)
     r.verbose = !quiet;
     r.setScene(scene);
     r.setSeeds(seed);
+    if (!resume_path.empty()) {
+        if (!r.loadCheckpoint(resume_path, &why)) { std::fprintf(stderr, "ERROR: %s\n", why.c_str()); return EXIT_FAILURE; }
+        std::printf("resumed %s at %d samples\n", resume_path.c_str(), r.numSamples());
+    }
     std::printf("%s: %zu spheres, %zu planes, %zu triangles, %dx%d, %d frames x %d spp\n", bdpt_version(),
                 scene.spheres.size(), scene.planes.size(), scene.triangles.size(), width, height, frames, spp);
 
@@ -101,6 +108,13 @@ int main(int argc, char **argv)
     std::printf("%d frames in %.3f s: %.2f Mpaths/s, %d samples accumulated\n", frames, sec, paths / sec / 1e6,
                 r.numSamples());
 
+    if (!checkpoint_path.empty()) {
+        if (!r.saveCheckpoint(checkpoint_path)) {
+            std::fprintf(stderr, "ERROR: cannot write %s\n", checkpoint_path.c_str());
+            return EXIT_FAILURE;
+        }
+        std::printf("checkpoint %s at %d samples\n", checkpoint_path.c_str(), r.numSamples());
+    }
     if (!out_path.empty()) {
         std::vector<float> img = r.readImage();
         if (!write_image(out_path, img.data(), width, height, 1.0f, gamma)) {

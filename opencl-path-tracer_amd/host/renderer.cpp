@@ -5,6 +5,7 @@
  */
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "bdpt_host.h"
 
@@ -70,6 +71,58 @@ std::vector<float> Renderer::readImage()
     std::vector<float> img((size_t)w * h * 4);
     check(bdpt_read_accum(c, img.data()), "bdpt_read_accum");
     return img;
+}
+
+namespace {
+struct CheckpointHeader {
+    char magic[8];                  /* "BDPTCKP1" */
+    int32_t width, height, num_samples, reserved;
+    bdpt_camera camera;
+};
+const char kCkptMagic[8] = {'B', 'D', 'P', 'T', 'C', 'K', 'P', '1'};
+}  // namespace
+
+bool Renderer::saveCheckpoint(const std::string &path)
+{
+    CheckpointHeader hd;
+    std::memset(&hd, 0, sizeof hd);
+    std::memcpy(hd.magic, kCkptMagic, 8);
+    hd.width = w;
+    hd.height = h;
+    hd.num_samples = bdpt_num_samples(c);
+    hd.camera = cam.getCLCamera();
+    std::vector<float> img((size_t)w * h * 4);
+    std::vector<uint32_t> seeds((size_t)w * h * 4);
+    check(bdpt_read_accum(c, img.data()), "bdpt_read_accum");
+    check(bdpt_read_seeds(c, seeds.data()), "bdpt_read_seeds");
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(img.data(), sizeof(float), img.size(), f) == img.size() &&
+                    std::fwrite(seeds.data(), sizeof(uint32_t), seeds.size(), f) == seeds.size();
+    return (std::fclose(f) == 0) && ok;
+}
+
+bool Renderer::loadCheckpoint(const std::string &path, std::string *err)
+{
+    auto bad = [&](const std::string &what) { if (err) *err = path + ": " + what; return false; };
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return bad("cannot open");
+    CheckpointHeader hd;
+    std::vector<float> img((size_t)w * h * 4);
+    std::vector<uint32_t> seeds((size_t)w * h * 4);
+    bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && !std::memcmp(hd.magic, kCkptMagic, 8);
+    if (!ok) { std::fclose(f); return bad("not a checkpoint file"); }
+    if (hd.width != w || hd.height != h || hd.num_samples < 0) { std::fclose(f); return bad("image size differs from this renderer's"); }
+    ok = std::fread(img.data(), sizeof(float), img.size(), f) == img.size() &&
+         std::fread(seeds.data(), sizeof(uint32_t), seeds.size(), f) == seeds.size();
+    std::fclose(f);
+    if (!ok) return bad("short read");
+    cam.setPose(hd.camera);
+    check(bdpt_set_camera(c, &hd.camera), "bdpt_set_camera");             /* zeroes the counter; restored below */
+    check(bdpt_upload_seeds(c, seeds.data()), "bdpt_upload_seeds");
+    check(bdpt_write_accum(c, img.data()), "bdpt_write_accum");
+    check(bdpt_set_num_samples(c, hd.num_samples), "bdpt_set_num_samples");
+    return true;
 }
 
 float Renderer::lastLaunchMs()

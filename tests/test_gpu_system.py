@@ -186,3 +186,43 @@ def test_c1_configuration_frame_loop_matches_the_oracle_at_full_size(bdpt):
     assert np.array_equal(out_seeds, st.seeds)
     assert np.array_equal(acc.view(np.uint32), st.accum.view(np.uint32))
     assert 0.15 < acc[..., :3].mean() < 0.45
+
+
+def test_checkpoint_and_resume_continue_bit_for_bit(bdpt, tmp_path):
+    """Host binary: 6 frames, checkpoint, then 6 more from the checkpoint in a new process == 12 frames straight;
+    and the same through the binding (read/write accumulator, seeds, sample counter)."""
+    exe = os.path.join(ROOT, "opencl-path-tracer_amd", "bdpt_host")
+    common = ["--width", "96", "--height", "64", "--spp", "2", "--quiet"]
+    ck, a, b = str(tmp_path / "s.ckpt"), str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    for args in (["--frames", "12", "--out", a], ["--frames", "6", "--checkpoint", ck],
+                 ["--frames", "6", "--resume", ck, "--out", b]):
+        r = subprocess.run([exe] + common + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert "resumed" in r.stdout and "24 samples accumulated" in r.stdout
+    assert open(a, "rb").read() == open(b, "rb").read()
+    bad = subprocess.run([exe, "--width", "64", "--height", "64", "--resume", ck], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "image size differs" in bad.stderr
+
+    scene = bdpt.Scene.cornell()
+    W, H = 64, 48
+
+    def fresh():
+        ctx = bdpt.Context(W, H)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(W, H, 9))
+        ctx.set_camera(scene.camera)
+        return ctx
+
+    with fresh() as ctx:
+        ctx.render(10)
+        straight = ctx.read_accum()
+    with fresh() as ctx:
+        ctx.render(4)
+        acc, seeds, n = ctx.read_accum(), ctx.read_seeds(), ctx.num_samples
+    with fresh() as ctx:
+        ctx.write_accum(acc)
+        ctx.upload_seeds(seeds)
+        ctx.num_samples = n
+        ctx.render(6)
+        resumed = ctx.read_accum()
+    assert np.array_equal(straight.view(np.uint32), resumed.view(np.uint32))

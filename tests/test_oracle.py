@@ -183,6 +183,68 @@ def test_search_order_and_max_distance(bdpt, oracle):
         assert oracle.ray_intersect(sc, (0.1, 0.2, -0.3), d)[0]
 
 
+def _closest_hit_f64(sc, o, d):
+    """Analytic closest hit in float64 with the reference's acceptance rules (kernel0.cl:232-361, :365-450), written
+    with numpy independently of the C restatement: returns (type, index, distance) or (-1, -1, inf)."""
+    o, d = np.asarray(o, np.float64), np.asarray(d, np.float64)
+    best = (-1, -1, 1.0e4)
+    for i, s in enumerate(sc.spheres):
+        oc = o - s["center"][:3].astype(np.float64)
+        b = d @ oc
+        disc = b * b - oc @ oc + float(s["radius"]) ** 2
+        if b > 0 or disc < 0:
+            continue
+        t = -b - np.sqrt(disc)
+        if t >= 0 and t < best[2]:
+            best = (0, i, t)
+    for i, p in enumerate(sc.planes):
+        n, pt = p["normal"][:3].astype(np.float64), p["point"][:3].astype(np.float64)
+        den = d @ n
+        if den >= 0:
+            continue
+        t = ((pt - o) @ n) / den
+        if t > 0 and t < best[2]:
+            best = (1, i, t)
+    for i, tr in enumerate(sc.triangles):
+        a, b, c = (tr[k][:3].astype(np.float64) for k in ("p0", "p1", "p2"))
+        n = np.cross(b - a, c - a)
+        if not n.any():
+            continue
+        n /= np.linalg.norm(n)
+        den = d @ n
+        if den > 0 or den == 0:
+            continue
+        t = ((a - o) @ n) / den
+        if t < 0:
+            continue
+        q = o + t * d
+        if min(np.cross(q - a, c - a) @ n, np.cross(q - c, b - c) @ n, np.cross(q - b, a - b) @ n) < 0:
+            continue
+        if t < best[2]:
+            best = (2, i, t)
+    return best if best[0] >= 0 else (-1, -1, np.inf)
+
+
+@pytest.mark.parametrize("which", ["cornell", "cornell_planes", "soup"])
+def test_closest_hit_agrees_with_float64_geometry(bdpt, oracle, which):
+    """800 random rays per scene: the restated search and an independent float64 computation name the same primitive
+    at the same point, except where float64 itself finds two candidates closer than 1e-4 (ties, edges, grazing hits)."""
+    sc = bdpt.Scene.soup(120) if which == "soup" else getattr(bdpt.Scene, which)()
+    rng = np.random.default_rng(11)
+    disagree = 0
+    for _ in range(800):
+        o = rng.uniform(-2.8, 2.8, 3).astype(np.float32)
+        d = rng.standard_normal(3)
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        hit, ids, pos, _ = oracle.ray_intersect(sc, o, d)
+        ty, ix, t = _closest_hit_f64(sc, o, d)
+        if hit and (ids[0], ids[1]) == (ty, ix):
+            assert np.allclose(pos, o.astype(np.float64) + t * d.astype(np.float64), atol=2e-5)
+        else:
+            disagree += 1
+    assert disagree <= 2, disagree
+
+
 def test_closest_hit_golden(bdpt, oracle):
     g = gu.load("closest_hit_cornell")
     sc = bdpt.Scene.cornell()

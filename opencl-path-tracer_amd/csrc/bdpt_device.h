@@ -339,8 +339,9 @@ BDPT_DEV constexpr uint32_t lcg_pow(int e)
 }
 
 /* Number of light-subpath vertices roulette allows a sample; same cost for every lane.  A sample
- * draws 9 numbers before its first roulette draw (2 pixel jitter, 3 light point, 4 first cone sample)
- * and 4 between one roulette draw and the next, so draw k is the start state times 48271^(9+4k). */
+ * draws 8 numbers before its first roulette draw (1 discarded, 2 pixel jitter, 2 light point, 3 first
+ * cone sample) and 3 between one roulette draw and the next, so roulette draw k is the generator's
+ * output number 9+4k: the start state times 48271^(9+4k). */
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
     int cls = K.max_l;

@@ -279,6 +279,46 @@ def test_light_sampler_lies_on_the_sphere(bdpt, oracle):
     assert abs(np.mean(ys)) < 0.05      # uniform over the sphere: mean height 0
 
 
+def _lcg_floats(seed, n):
+    out, w = [], seed
+    for _ in range(n):
+        w = (w * 48271) & 0xFFFFFFFF
+        out.append(w / 4294967296.0)
+    return out, w
+
+
+def test_samplers_follow_the_reference_formulas_in_float64(bdpt, oracle):
+    """The two samplers against their formulas (kernel0.cl:155-185, :547-569) evaluated in float64 from the same
+    draws: cone = cos(a) n + sin(a) (cos(b) t1 + sin(b) t2), a = (1 - acos(u0) 2/pi) half_angle, b = 2 pi u1,
+    t1 = normalize(n x (2 u2 - 1, 0, 1)), t2 = n x t1; light point = c + r (sin th sin ph, cos th, sin th cos ph),
+    th = acos(1 - 2 u0), ph = 2 pi u1."""
+    rng = np.random.default_rng(8)
+    light = bdpt.Scene.cornell().spheres[0:1]
+    c, r = light["center"][0, :3].astype(np.float64), float(light["radius"][0])
+    for _ in range(400):
+        seed = int(rng.integers(1, 2**32)) | 1
+        n = rng.standard_normal(3)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        half = np.float32(3.1415 * 0.5)
+        got, w_after = oracle.sample_cone(seed, n, half)
+        (u0, u1, u2), w = _lcg_floats(seed, 3)
+        assert w_after == w                                      # three draws, in this order
+        n64 = n.astype(np.float64)
+        t1 = np.cross(n64, (2 * u2 - 1, 0.0, 1.0))
+        t1 /= np.linalg.norm(t1)
+        t2 = np.cross(n64, t1)
+        a, b = (1 - math.acos(u0) * 2 / math.pi) * float(half), 6.283185307 * u1
+        want = math.cos(a) * n64 + math.sin(a) * (math.cos(b) * t1 + math.sin(b) * t2)
+        assert np.allclose(got, want, atol=3e-6), (seed, got, want)
+
+        pos, nrm, w_after = oracle.sample_sphere(seed, light)
+        (v0, v1), w = _lcg_floats(seed, 2)
+        assert w_after == w
+        th, ph = math.acos(1 - 2 * v0), 2 * math.pi * v1
+        dirn = np.array([math.sin(th) * math.sin(ph), math.cos(th), math.sin(th) * math.cos(ph)])
+        assert np.allclose(nrm, dirn, atol=3e-6) and np.allclose(pos, c + r * dirn, atol=3e-6)
+
+
 def test_camera_ray_through_the_screen_centre_is_the_look_direction(bdpt, oracle):
     cam = bdpt.Scene.cornell().camera
     d = oracle.shoot_ray(cam, 0.0, 0.0)

@@ -86,6 +86,17 @@ enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
  *                 light loop (closed scenes) and costs when most eye rays leave the scene.
  * AUTO:           ROULETTE_CLASS when it is allowed, else INDEX. */
 enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2 };
+/* How a light-subpath vertex picks its bounce direction.  The live code calls brdf_lambertian
+ * (kernel0.cl:767); the file holds two more samplers that nothing calls, offered here as they stand:
+ * LAMBERT_CONE: brdf_lambertian, kernel0.cl:484-490 -- random_sample_cone about the normal with
+ *               half-angle 3.1415f*0.5f (three draws).
+ * HEMISPHERE:   random_sample_hemisphere, kernel0.cl:117-153, about the normal: elevation uniform
+ *               in angle (three draws).
+ * REFLECTIVE:   brdf_reflective, kernel0.cl:492-508: one more draw p4 first; p4 > 0.6f samples a
+ *               cone of half-angle 3.1415f*0.02f about the mirror image of the direction the subpath
+ *               arrived from (the zero vector at the light, as kernel0.cl:659 initialises it), else
+ *               the Lambert cone (four draws).  Not available in the DUAL kernel variant. */
+enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_REFLECTIVE = 2 };
 /* Kernel variants; all give identical results.
  * DIRECT: every lane walks the primitive arrays with wave-uniform scalar loads.
  * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
@@ -122,6 +133,7 @@ typedef struct bdpt_params {
     int32_t aov_enable;         /* maintain the bdpt_read_aov() buffers */
     int32_t kernel_variant;     /* BDPT_KERNEL_* */
     int32_t sample_order;       /* BDPT_ORDER_* */
+    int32_t sampler;            /* BDPT_SAMPLER_* */
 } bdpt_params;
 
 typedef struct bdpt_ctx bdpt_ctx;

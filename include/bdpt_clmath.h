@@ -80,6 +80,17 @@ CLM_FN clm_f3 clm_normalize3(clm_f3 a)
     return clm_scale3(inv, a);
 }
 
+/* (-2 * n * dot(n, v)) + v, evaluated left to right, each operation rounded (kernel0.cl:495). */
+CLM_FN clm_f3 clm_reflect3(clm_f3 n, clm_f3 v)
+{
+    float dn = clm_dot3(n, v);
+    clm_f3 r;
+    r.x = ((-2.0f * n.x) * dn) + v.x;
+    r.y = ((-2.0f * n.y) * dn) + v.y;
+    r.z = ((-2.0f * n.z) * dn) + v.z;
+    return r;
+}
+
 /* sign(): 1, -1, the zero itself, or 0 for NaN. */
 CLM_FN float clm_sign(float x)
 {

@@ -31,6 +31,7 @@ FALLOFF_INV_SQ, FALLOFF_INV_SQ_PLUS_C = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_DUAL, KERNEL_LDS, KERNEL_TILED = 0, 1, 2, 3, 4
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS = 0, 1, 2
+SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE = 0, 1, 2
 AOV_EYE_HIT, AOV_HIT_HASH, AOV_RADIANCE, AOV_RNG_DRAWS, AOV_RAYS = 0, 1, 2, 3, 4
 SCENE_CORNELL, SCENE_PLANES, SCENE_OUTDOOR, SCENE_SOUP = 0, 1, 2, 3
 
@@ -50,6 +51,7 @@ class Params(C.Structure):
         ("aov_enable", C.c_int32),
         ("kernel_variant", C.c_int32),
         ("sample_order", C.c_int32),
+        ("sampler", C.c_int32),
     ]
 
 

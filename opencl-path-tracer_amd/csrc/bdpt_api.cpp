@@ -118,6 +118,7 @@ void bdpt_default_params(bdpt_params *p)
     p->aov_enable = 0;
     p->kernel_variant = BDPT_KERNEL_AUTO;
     p->sample_order = BDPT_ORDER_AUTO;
+    p->sampler = BDPT_SAMPLER_LAMBERT_CONE;
 }
 
 int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
@@ -230,6 +231,10 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
     if (p->sample_order == BDPT_ORDER_ROULETTE_CLASS && !(p->rng_mode == BDPT_RNG_STRIDED && p->accum_mode == BDPT_ACCUM_SUM))
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS needs rng_mode STRIDED and accum_mode SUM");
+    if (p->sampler < BDPT_SAMPLER_LAMBERT_CONE || p->sampler > BDPT_SAMPLER_REFLECTIVE)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sampler");
+    if (p->sampler != BDPT_SAMPLER_LAMBERT_CONE && p->kernel_variant == BDPT_KERNEL_DUAL)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: the DUAL kernel variant has the LAMBERT_CONE sampler only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->params = *p;
     if (p->aov_enable) return ensure_aovs(ctx);
@@ -464,6 +469,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.falloff = P.connection_falloff;
     K.falloff_c = P.falloff_c;
     K.accum_mode = P.accum_mode;
+    K.sampler = P.sampler;
     K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.sample_order != BDPT_ORDER_INDEX) ? 1 : 0;
     /* (float)x * 2^-32 > p_con, the roulette test of kernel0.cl:788, as an integer test x > fate_above: the
      * conversion is monotone in x and the scaling exact, so there is one such threshold */

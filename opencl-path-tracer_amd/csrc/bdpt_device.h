@@ -62,6 +62,35 @@ BDPT_DEV clm_f3 sample_cone(uint32_t &w, uint32_t &draws, clm_f3 axis, float hal
     return clm_mad3(sl, ring, clm_scale3(cl, axis));
 }
 
+/* kernel0.cl:117-153 random_sample_hemisphere */
+BDPT_DEV clm_f3 sample_hemisphere(uint32_t &w, uint32_t &draws, clm_f3 axis)
+{
+    float p0 = rng_float(w, draws);
+    float p1 = rng_float(w, draws);
+    float p2 = rng_float(w, draws);
+    clm_f3 helper = clm_make3((float)((double)p2 * 2.0 - 1.0), 0.0f, 1.0f);          /* :127 */
+    clm_f3 t1 = clm_normalize3(clm_cross3(axis, helper));                            /* :132 */
+    clm_f3 t2 = clm_cross3(axis, t1);                                                /* :134 */
+    float sweep = p1 * 6.283185307f;                                                 /* :141 */
+    float lift = p0 * 1.570796326f;                                                  /* :142 */
+    float sl, cl, ss, cs;
+    clm_sincos(lift, &sl, &cl);
+    clm_sincos(sweep, &ss, &cs);
+    clm_f3 ring = clm_mad3(ss, t2, clm_scale3(cs, t1));                              /* :150 */
+    return clm_mad3(sl, ring, clm_scale3(cl, axis));
+}
+
+/* the samplers other than the live one (kernel0.cl:767): hemisphere, or brdf_reflective :492-508 */
+BDPT_DEV clm_f3 sample_bounce_alt(const bdpt_kargs &K, uint32_t &w, uint32_t &draws, clm_f3 n, clm_f3 incoming)
+{
+    if (K.sampler == BDPT_SAMPLER_HEMISPHERE) return sample_hemisphere(w, draws, n);
+    const float p4 = rng_float(w, draws);                                            /* :493 */
+    const bool mirror = p4 > 0.6f;                                                   /* :500 */
+    const clm_f3 r = clm_reflect3(n, incoming);                                      /* :495 */
+    const clm_f3 axis = mirror ? r : n;
+    return sample_cone(w, draws, axis, mirror ? 3.1415f * 0.02f : 3.1415f * 0.50f);  /* :501, :503 */
+}
+
 /* kernel0.cl:547-569 sampleSphereSurface: point and outward normal on the light */
 BDPT_DEV void sample_light(uint32_t &w, uint32_t &draws, const bdpt_kargs &K, clm_f3 &pos, clm_f3 &nrm)
 {
@@ -344,11 +373,13 @@ BDPT_DEV constexpr uint32_t lcg_pow(int e)
  * output number 9+4k: the start state times 48271^(9+4k). */
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
+    const bool five = K.sampler == BDPT_SAMPLER_REFLECTIVE;    /* one more draw per vertex: 10 + 5k */
+    const uint32_t step = five ? lcg_pow(5) : lcg_pow(4);
     int cls = K.max_l;
-    uint32_t x = start_state * lcg_pow(9);
+    uint32_t x = start_state * (five ? lcg_pow(10) : lcg_pow(9));
     for (int k = 0; k + 1 < K.max_l; k++) {
         cls = (x > K.fate_above && cls == K.max_l) ? k + 1 : cls;                    /* :788 */
-        x *= lcg_pow(4);
+        x *= step;
     }
     return cls;
 }

@@ -118,7 +118,8 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
 /* One sample (kernel0.cl:592-847).  Returns true when the reference would have
  * returned early (eye ray missed or hit a light, :645-656); col is then the raw
  * value it writes. */
-template <bool AOV, int MODE>
+/* ALT: bounce directions from one of the samplers the reference holds but does not call (K.sampler) */
+template <bool AOV, int MODE, bool ALT>
 BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                             uint32_t &hash, int eye_id[2], float col[4])
 {
@@ -149,6 +150,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
     float pre = K.pre_factor0;                                            /* :694 */
     int taken = 0;
+    clm_f3 incoming = clm_make3(0.0f, 0.0f, 0.0f);                        /* :659 */
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
         clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));            /* :699 */
         Hit vis = trace_one<MODE, true>(S, vpos, tdir, vtype, vidx);         /* :705 */
@@ -164,7 +166,8 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         taken++;                                                          /* :757 */
 
         clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                       /* :761 */
-        clm_f3 ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);         /* :767, :486 */
+        clm_f3 ldir = ALT ? sample_bounce_alt(K, w, draws, vn, incoming)
+                          : sample_cone(w, draws, vn, 3.1415f * 0.50f);   /* :767, :486 */
         float fate = rng_float(w, draws);                                 /* :787 */
         if (fate > K.p_con) break;                                        /* :788 */
 
@@ -176,6 +179,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         const float4 ne = S.surf[nxt.surf * 2 + 1];
         if (ne.w != 0.0f) break;                                          /* :797-803 */
         acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
+        if (ALT) incoming = ldir;                                         /* :831 */
         vpos = nxt.pos; vn = nxt.n; vtype = nxt.type; vidx = nxt.idx;     /* :832 */
     }
 
@@ -194,7 +198,7 @@ template <bool AOV>
 BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                           uint32_t &hash, int eye_id[2], float col[4]);   /* defined below */
 
-template <bool AOV, bool COUNT, int MODE>
+template <bool AOV, bool COUNT, int MODE, bool ALT>
 __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                             : sample_direct<AOV, MODE>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+                                             : sample_direct<AOV, MODE, ALT>(K, xt, yt, w, draws, rays, hash, eye_id, col);
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -436,7 +440,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
 }
 
 /* sample_direct with every early exit turned into the `alive` predicate (see above) */
-template <bool AOV>
+template <bool AOV, bool ALT>
 BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, float xt, float yt, uint32_t &w,
                            uint32_t &draws, uint32_t &rays, uint32_t &hash, int eye_id[2], float col[4])
 {
@@ -473,6 +477,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
     float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
     float pre = K.pre_factor0;                                            /* :694 */
     int taken = 0;
+    clm_f3 incoming = clm_make3(0.0f, 0.0f, 0.0f);                        /* :659 */
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;               /* wave-uniform */
         clm_f3 tdir = clm_make3(0.f, 0.f, 1.f);
@@ -490,7 +495,8 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
             }
             taken++;                                                      /* :757 */
             lpos = clm_mad3(0.00001f, vn, vpos);                          /* :761 */
-            ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);            /* :767, :486 */
+            ldir = ALT ? sample_bounce_alt(K, w, draws, vn, incoming)
+                       : sample_cone(w, draws, vn, 3.1415f * 0.50f);      /* :767, :486 */
             const float fate = rng_float(w, draws);                       /* :787 */
             if (fate > K.p_con) alive = false;                            /* :788 */
         }
@@ -508,6 +514,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
                     alive = false;
                 } else {
                     acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
+                    if (ALT) incoming = ldir;                             /* :831 */
                     vpos = nxt.pos; vn = nxt.n; vtype = nxt.type; vidx = nxt.idx;     /* :832 */
                 }
             }
@@ -526,7 +533,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
     return early;
 }
 
-template <bool AOV, bool COUNT>
+template <bool AOV, bool COUNT, bool ALT>
 __global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
 {
     __shared__ float4 tiles[4][2 * BDPT_TILE_F4];
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = sample_tiled<AOV>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
+        const bool early = sample_tiled<AOV, ALT>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
         if (!live) continue;
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -663,10 +670,22 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
         lds = bdpt_lds_scene_bytes(K.scene);
         if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
     }
-    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, true, MODE>), grid, block, lds, stream, K);
-    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<true, false, MODE>), grid, block, lds, stream, K);
-    else if (count) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, true, MODE>), grid, block, lds, stream, K);
-    else hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<false, false, MODE>), grid, block, lds, stream, K);
+    const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
+    if (alt && MODE == bdpt::MODE_DUAL) return hipErrorInvalidValue;
+#define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<A, C, MODE, X>), grid, block, lds, stream, K)
+    if (alt) {
+        constexpr bool X = MODE != bdpt::MODE_DUAL;      /* the DUAL kernel has no such instantiation */
+        if (aov && count) BDPT_LAUNCH(true, true, X);
+        else if (aov) BDPT_LAUNCH(true, false, X);
+        else if (count) BDPT_LAUNCH(false, true, X);
+        else BDPT_LAUNCH(false, false, X);
+    } else {
+        if (aov && count) BDPT_LAUNCH(true, true, false);
+        else if (aov) BDPT_LAUNCH(true, false, false);
+        else if (count) BDPT_LAUNCH(false, true, false);
+        else BDPT_LAUNCH(false, false, false);
+    }
+#undef BDPT_LAUNCH
     return hipGetLastError();
 }
 
@@ -694,10 +713,20 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
     dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
-    if (aov && count) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<true, true>), grid, block, 0, stream, K);
-    else if (aov) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<true, false>), grid, block, 0, stream, K);
-    else if (count) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<false, true>), grid, block, 0, stream, K);
-    else hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<false, false>), grid, block, 0, stream, K);
+    const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
+#define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, 0, stream, K)
+    if (alt) {
+        if (aov && count) BDPT_LAUNCH(true, true, true);
+        else if (aov) BDPT_LAUNCH(true, false, true);
+        else if (count) BDPT_LAUNCH(false, true, true);
+        else BDPT_LAUNCH(false, false, true);
+    } else {
+        if (aov && count) BDPT_LAUNCH(true, true, false);
+        else if (aov) BDPT_LAUNCH(true, false, false);
+        else if (count) BDPT_LAUNCH(false, true, false);
+        else BDPT_LAUNCH(false, false, false);
+    }
+#undef BDPT_LAUNCH
     return hipGetLastError();
 }
 

@@ -75,6 +75,7 @@ struct bdpt_kargs {
     int falloff;
     float falloff_c;
     int accum_mode;
+    int sampler;                /* BDPT_SAMPLER_* */
     /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
      * gives their light subpath (see SampleCursor in bdpt_device.h) */
     int reorder;

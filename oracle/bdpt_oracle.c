@@ -103,6 +103,35 @@ static clm_f3 random_sample_cone(Lane *L, clm_f3 vDir, float halfAngle)
     return clm_mad3(s0, inner, clm_scale3(c0, vDir));
 }
 
+/* ---- random_sample_hemisphere, kernel0.cl:117-153 --------------------------- */
+
+static clm_f3 random_sample_hemisphere(Lane *L, clm_f3 vDir)
+{
+    float p0 = get_rng_float(L);
+    float p1 = get_rng_float(L);
+    float p2 = get_rng_float(L);
+    clm_f3 vecRand = clm_make3((float)((double)p2 * 2.0 - (double)1.0f), 0.0f, 1.0f);   /* :127 */
+    clm_f3 vPerp = clm_normalize3(clm_cross3(vDir, vecRand));           /* :132 */
+    clm_f3 vPerp2 = clm_cross3(vDir, vPerp);                            /* :134 */
+    p1 = p1 * 6.283185307f;                                             /* :141 */
+    p0 = p0 * 1.570796326f;                                             /* :142 */
+    float s0, c0, s1, c1;
+    clm_sincos(p0, &s0, &c0);
+    clm_sincos(p1, &s1, &c1);
+    clm_f3 inner = clm_mad3(s1, vPerp2, clm_scale3(c1, vPerp));         /* :150 */
+    return clm_mad3(s0, inner, clm_scale3(c0, vDir));
+}
+
+/* ---- brdf_reflective, kernel0.cl:492-508 ------------------------------------ */
+
+static clm_f3 brdf_reflective(Lane *L, clm_f3 normal, clm_f3 vDir)
+{
+    float p4 = get_rng_float(L);                                        /* :493 */
+    clm_f3 reflected = clm_reflect3(normal, vDir);                      /* :495 */
+    if (p4 > 0.6f) return random_sample_cone(L, reflected, 3.1415f * 0.02f);   /* :500-501 */
+    return random_sample_cone(L, normal, 3.1415f * 0.50f);              /* :503 */
+}
+
 /* ---- findRandomPoint, kernel0.cl:190-202 ----------------------------------- */
 
 static void findRandomPoint(Lane *L, float blur, int W, int H, float pixx, float pixy,
@@ -370,6 +399,7 @@ static Sample trace_sample(Lane *L, const orc_job *J, const Scene *sc, int x, in
     float accContrib[4] = {1, 1, 1, 1};                                   /* :692 */
     float preFactor = clm_div(1.0f - pCon, 1.0f - clm_powi(pCon, maxL));  /* :694 */
     int samplesTaken = 0;
+    clm_f3 incomingDir = clm_make3(0.0f, 0.0f, 0.0f);                     /* :659 */
 
     for (int lti = 0; lti < maxL; lti++) {                                /* :696 */
         clm_f3 testDir = clm_normalize3(clm_sub3(vTestPos, patch.k.pos)); /* :699 */
@@ -402,7 +432,10 @@ static Sample trace_sample(Lane *L, const orc_job *J, const Scene *sc, int x, in
 
         clm_f3 launchRef = patch.n;                                       /* :760 */
         clm_f3 launchPos = clm_mad3(0.00001f, patch.n, patch.k.pos);      /* :761 */
-        clm_f3 launchDir = random_sample_cone(L, launchRef, 3.1415f * 0.50f);   /* :767, :486 */
+        clm_f3 launchDir;
+        if (P->sampler == BDPT_SAMPLER_HEMISPHERE) launchDir = random_sample_hemisphere(L, launchRef);
+        else if (P->sampler == BDPT_SAMPLER_REFLECTIVE) launchDir = brdf_reflective(L, launchRef, incomingDir);
+        else launchDir = random_sample_cone(L, launchRef, 3.1415f * 0.50f);   /* :767, :486 */
 
         float fate = get_rng_float(L);                                    /* :787 */
         if (fate > pCon) break;                                           /* :788 */
@@ -416,6 +449,7 @@ static Sample trace_sample(Lane *L, const orc_job *J, const Scene *sc, int x, in
         /* :822, :824 force samplingFactor = directionalFactor = 1.0f */
         for (int k = 0; k < 4; k++)                                       /* :827 */
             accContrib[k] *= target.diffuse[k] * 1.0f * 1.0f * 1.0f;
+        incomingDir = launchDir;                                          /* :831 */
         patch = target;                                                   /* :832 */
     }
 
@@ -441,15 +475,17 @@ static uint32_t pow_u32(uint32_t base, uint32_t e)
 }
 
 /* Class of a STRIDED sample: the number of light-subpath vertices Russian roulette allows it
- * (the draws at kernel0.cl:787 are draws 9, 13, 17, ... of the sample and depend on nothing else). */
+ * (the draws at kernel0.cl:787 are draws 9, 13, 17, ... of the sample -- 10, 15, 20, ... with the
+ * reflective sampler's extra draw per vertex -- and depend on nothing else). */
 static int roulette_class(const bdpt_params *P, uint32_t start_state)
 {
+    const int per_vertex = P->sampler == BDPT_SAMPLER_REFLECTIVE ? 5 : 4;   /* draws from one roulette draw to the next */
     uint32_t w = start_state;
-    for (int j = 0; j < 9; j++) w *= 48271u;
+    for (int j = 0; j < 5 + per_vertex; j++) w *= 48271u;
     for (int k = 0; k + 1 < P->max_light_bounces; k++) {
         float fate = clm_div((float)w, 4294967296.0f);
         if (fate > P->p_continue) return k + 1;
-        for (int j = 0; j < 4; j++) w *= 48271u;
+        for (int j = 0; j < per_vertex; j++) w *= 48271u;
     }
     return P->max_light_bounces;
 }

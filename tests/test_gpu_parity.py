@@ -261,6 +261,39 @@ def test_sample_orders_take_the_same_samples(bdpt, oracle, variant, p_continue, 
     np.testing.assert_allclose(a[0], b[0], rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("sampler", [1, 2])
+def test_alternative_samplers_match_the_oracle(bdpt, oracle, variant, sampler):
+    """HEMISPHERE and REFLECTIVE bounce samplers: per-sample parity in STREAM mode and a class-ordered STRIDED + SUM
+    launch, on every kernel variant that has them."""
+    scene = bdpt.Scene.cornell()
+    W, H = 48, 40
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=41, kernel_variant=variant, sampler=sampler)
+    for s in range(6):
+        ctx.render(1)
+        oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
+        _compare(bdpt, ctx, st, "sampler %d sample %d:" % (sampler, s))
+    ctx.render(5)
+    oracle.render(st, scene, scene.camera, p, 5, n_threads=8)
+    _compare(bdpt, ctx, st, "sampler %d batch:" % sampler)
+    ctx.close()
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=43, kernel_variant=variant, sampler=sampler,
+                       rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    ctx.render(45)
+    oracle.render(st, scene, scene.camera, p, 45, n_threads=8)
+    _compare(bdpt, ctx, st, "sampler %d strided sum:" % sampler)
+    ctx.close()
+
+
+def test_dual_variant_has_only_the_live_sampler(bdpt):
+    ctx = bdpt.Context(16, 16)
+    with pytest.raises(bdpt.BdptError, match="DUAL"):
+        ctx.set_params(bdpt.default_params(kernel_variant=bdpt.KERNEL_DUAL, sampler=bdpt.SAMPLER_REFLECTIVE))
+    with pytest.raises(bdpt.BdptError, match="sampler"):
+        ctx.set_params(bdpt.default_params(sampler=7))
+    ctx.close()
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

@@ -381,6 +381,33 @@ def test_draw_and_ray_counts_follow_the_loop_structure(bdpt, oracle):
     assert ((r == 1 + 2 * it) | (r == 2 * it)).all()
 
 
+def test_alternative_samplers_change_the_draw_pattern_not_the_structure(bdpt, oracle):
+    """HEMISPHERE draws like the live sampler (4 per iteration); REFLECTIVE draws one more number per vertex
+    (kernel0.cl:493).  At the light the incoming direction is the zero vector (:659), so a mirror pick there (p4 > 0.6)
+    yields a NaN direction that hits nothing: the walk ends after that bounce ray."""
+    sc = bdpt.Scene.cornell()
+    base, _, _ = _render(bdpt, oracle, sc, 48, 48, 1)
+    full = base.eye_hit[..., 0] >= 0
+    full &= ~((base.eye_hit[..., 0] == 0) & (base.eye_hit[..., 1] == 0))
+    hemi, _, _ = _render(bdpt, oracle, sc, 48, 48, 1, sampler=bdpt.SAMPLER_HEMISPHERE)
+    d = hemi.rng_draws[full].astype(int)
+    assert ((d - 5) % 4 == 0).all() and np.array_equal(hemi.eye_hit, base.eye_hit)
+    assert not np.array_equal(hemi.radiance, base.radiance) and np.isfinite(hemi.radiance).all()
+    refl, _, _ = _render(bdpt, oracle, sc, 48, 48, 1, sampler=bdpt.SAMPLER_REFLECTIVE)
+    d, r = refl.rng_draws[full].astype(int), refl.rays[full].astype(int)
+    it = (d - 5) // 5
+    assert ((d - 5) % 5 == 0).all() and (it >= 1).all() and (it <= 5).all()
+    assert ((r == 1 + 2 * it) | (r == 2 * it)).all() and np.isfinite(refl.radiance).all()
+    # more walks stop after one vertex than Russian roulette alone would stop (20 %)
+    assert (it == 1).mean() > 0.4
+    # a STRIDED + SUM launch takes the same samples in either order (the class follows draws 10, 15, ...)
+    kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, sampler=bdpt.SAMPLER_REFLECTIVE)
+    a, _, _ = _render(bdpt, oracle, sc, 32, 24, 24, sample_order=bdpt.ORDER_INDEX, **kw)
+    b, _, _ = _render(bdpt, oracle, sc, 32, 24, 24, sample_order=bdpt.ORDER_ROULETTE_CLASS, **kw)
+    assert np.array_equal(a.rng_draws, b.rng_draws) and np.array_equal(a.rays, b.rays)
+    np.testing.assert_allclose(a.accum, b.accum, rtol=2e-5, atol=1e-5)
+
+
 def test_running_mean_is_the_mean_of_the_samples(bdpt, oracle):
     sc = bdpt.Scene.cornell()
     st, _, rads = _render(bdpt, oracle, sc, 40, 24, 12, per_sample=True)

@@ -216,7 +216,12 @@ def main():
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
             "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
         }
-        out["hbm_gbps_algorithmic"] = round(W * H * 36 / avg_s / 1e9, 3)   # 16 B read + 16 B write + 4 B seed per pixel per launch
+        # the same launch against the HBM roofline, to show that it is not the one that binds:
+        # 16 B accumulator read + 16 B write + 4 B seed word per pixel per launch, whatever spp is
+        hbm = W * H * 36 / avg_s / 1e9
+        out["roofline_hbm"] = {"bound": "hbm", "achieved": round(hbm, 3), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(hbm / 8000.0, 6), "traffic": out["roofline"]["traffic"],
+                               "algorithmic_bytes": W * H * 36}
         # the same frame with the reference's sequential generator and running-mean blend (one launch, untimed above):
         # samples are taken in index order there, so the wavefronts pay for roulette divergence
         if args.stream_line:

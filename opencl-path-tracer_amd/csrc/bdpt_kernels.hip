@@ -198,8 +198,12 @@ template <bool AOV>
 BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                           uint32_t &hash, int eye_id[2], float col[4]);   /* defined below */
 
+/* Six wavefronts per SIMD (80 VGPRs, a handful of spills) measure 4.5 % faster than the five the
+ * register allocator would settle for at 94 VGPRs; seven and eight spill too much.  The two-ray
+ * variant needs its registers. */
 template <bool AOV, bool COUNT, int MODE, bool ALT>
-__global__ __launch_bounds__(256) void bdpt_direct_kernel(const bdpt_kargs K)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : 6, MODE == MODE_DUAL ? 4 : 6)))
+void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

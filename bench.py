@@ -157,8 +157,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up that is not a step: load the code object and, for N > 1, build the communicator (both happen on first use)
-    ctx.render(1)
+    # set-up that is not a step: for N > 1, build the communicator (it is built on first use)
     if world > 1:
         probe = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(probe)

@@ -378,8 +378,11 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * the triangle records through its own LDS buffer in tiles of BDPT_TILE_TRIS:
  * all 64 lanes copy the tile with coalesced float4 loads (lane l copies float4
  * l, l+64, ... of the tile), then every lane walks the tile with wave-uniform
- * ds_read_b128 broadcasts, exactly as the LDS-resident variant walks the whole
- * scene.  Two buffers per wavefront: the global loads of tile k+1 are issued
+ * ds_read_b128 broadcasts, as the LDS-resident variant walks the whole scene.
+ * The tiles hold compact records (three float4 per triangle, bdpt_layout.h):
+ * this kernel moves every triangle through L2 and LDS once per ray, and half
+ * the bytes are worth the nine subtractions that rebuild the edge vectors.
+ * Two buffers per wavefront: the global loads of tile k+1 are issued
  * before tile k is walked and written to the other buffer afterwards.
  *
  * The copy needs every lane of the wavefront, so the sample is written with a
@@ -389,8 +392,8 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * wavefronts of a workgroup run independently.                                 */
 /* ------------------------------------------------------------------------- */
 
-#define BDPT_TILE_TRIS 32
-#define BDPT_TILE_F4 (BDPT_TILE_TRIS * BDPT_TRI_F4)      /* 192 float4 = 3 per lane */
+#define BDPT_TILE_TRIS 64
+#define BDPT_TILE_F4 (BDPT_TILE_TRIS * BDPT_TRI3_F4)     /* 192 float4 of compact records = 3 per lane */
 
 BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool active, clm_f3 o, clm_f3 d, int otype,
                                int oidx)
@@ -412,13 +415,13 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         }
     }
     const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
-    const size_t total_f4 = (size_t)(S.n_triangles + 1) * BDPT_TRI_F4;     /* the array is padded by one record */
+    const size_t total_f4 = (size_t)(S.n_triangles + 1) * BDPT_TRI3_F4;    /* the array is padded by one record */
     float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */
     auto fetch = [&](int tile) {
         const size_t base = (size_t)tile * BDPT_TILE_F4 + lane;
-        r0 = S.tri[base < total_f4 ? base : 0];
-        r1 = S.tri[base + 64 < total_f4 ? base + 64 : 0];
-        r2 = S.tri[base + 128 < total_f4 ? base + 128 : 0];
+        r0 = S.tri3[base < total_f4 ? base : 0];
+        r1 = S.tri3[base + 64 < total_f4 ? base + 64 : 0];
+        r2 = S.tri3[base + 128 < total_f4 ? base + 128 : 0];
     };
     if (n_tiles > 0) fetch(0);
     for (int tile = 0; tile < n_tiles; tile++) {
@@ -432,10 +435,8 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             const int first = tile * BDPT_TILE_TRIS;
             const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
             for (int j = 0; j < count; j++) {
-                const float4 *q = buf + j * BDPT_TRI_F4;
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-                const float e2z = q[5].x;
-                test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, first + j, skip_t, o, d);
+                const float4 *q = buf + j * BDPT_TRI3_F4;
+                test_triangle_scattered_c(b, q[0], q[1], q[2], first + j, skip_t, o, d);
             }
         }
         __builtin_amdgcn_wave_barrier();

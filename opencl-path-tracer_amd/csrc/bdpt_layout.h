@@ -18,6 +18,10 @@
  *       q4 (b.y,  b.z,  e2.x, e2.y)   e2 = a-b
  *       q5 (e2.z, ns.x, ns.y, ns.z)   ns = normalize(cross(a-b, b-c)), the
  *                                     shading normal of kernel0.cl:467
+ *   triangle, compact, 3 x float4 : (n.xyz, a.x) (a.y, a.z, b.x, b.y) (b.z, c.xyz)
+ *       what the tiled kernel streams (half the bytes per triangle through L2 and LDS);
+ *       the three edge vectors are one subtraction each from the vertices, the same
+ *       subtraction the upload does for q1-q5
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
  * winning primitive only).
@@ -29,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #define BDPT_TRI_F4 6
+#define BDPT_TRI3_F4 3
 #define BDPT_PLN_F4 2
 
 struct bdpt_dev_scene {
@@ -36,7 +41,8 @@ struct bdpt_dev_scene {
     const uint32_t *sph_surf;   /* [n_spheres] */
     const float4 *pln;          /* [n_planes * BDPT_PLN_F4] */
     const uint32_t *pln_surf;   /* [n_planes] */
-    const float4 *tri;          /* [n_triangles * BDPT_TRI_F4] */
+    const float4 *tri;          /* [(n_triangles + 1) * BDPT_TRI_F4] */
+    const float4 *tri3;         /* [(n_triangles + 1) * BDPT_TRI3_F4], compact records */
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;

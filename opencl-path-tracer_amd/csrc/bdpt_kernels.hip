@@ -8,7 +8,7 @@
  * accumulator is read and written once per launch (one float4 per pixel).
  *
  * Lane -> pixel: a wavefront covers an 8x8 pixel tile (lane & 7 = x, lane >> 3
- * = y), a 256-thread workgroup four tiles side by side (32x8 pixels), so that
+ * = y), a workgroup BDPT_BLOCK / 64 tiles side by side, so that
  * the eye rays of a wavefront stay coherent and silhouette edges cut through as
  * few wavefronts as possible.
  *
@@ -18,6 +18,11 @@
 #include "bdpt_device.h"
 #include "bdpt_device2.h"
 #include "bdpt_kernels.h"
+
+/* Workgroup: two wavefronts, i.e. two 8x8 pixel tiles side by side (measured against one and four:
+ * 245.9 / 248.2 / 249.9 ms per 1024-spp Cornell launch for 128 / 64 / 256 threads). */
+#define BDPT_BLOCK 128
+#define BDPT_BLOCK_W (BDPT_BLOCK / 8)
 
 namespace bdpt {
 
@@ -202,12 +207,12 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * register allocator would settle for at 94 VGPRs; seven and eight spill too much.  The two-ray
  * variant needs its registers. */
 template <bool AOV, bool COUNT, int MODE, bool ALT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : 6, MODE == MODE_DUAL ? 4 : 6)))
+__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : 6, MODE == MODE_DUAL ? 4 : 6)))
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
+    const int x = K.rx0 + (int)blockIdx.x * BDPT_BLOCK_W + wv * 8 + (lane & 7);
     const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
     if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
     const size_t pix = (size_t)y * K.width + x;
@@ -539,12 +544,12 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
 }
 
 template <bool AOV, bool COUNT, bool ALT>
-__global__ __launch_bounds__(256) void bdpt_tiled_kernel(const bdpt_kargs K)
+__global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs K)
 {
-    __shared__ float4 tiles[4][2 * BDPT_TILE_F4];
+    __shared__ float4 tiles[BDPT_BLOCK / 64][2 * BDPT_TILE_F4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float4 *wave_lds = tiles[wv];
-    const int x = K.rx0 + (int)blockIdx.x * 32 + wv * 8 + (lane & 7);
+    const int x = K.rx0 + (int)blockIdx.x * BDPT_BLOCK_W + wv * 8 + (lane & 7);
     const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
     const bool inside = x < K.rx0 + K.rw && y < K.ry0 + K.rh;             /* lanes outside still help copy tiles */
     const size_t pix = inside ? (size_t)y * K.width + x : 0;
@@ -669,7 +674,7 @@ template <int MODE>
 static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
+    dim3 grid((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8), block(BDPT_BLOCK);
     size_t lds = 0;
     if (MODE == bdpt::MODE_LDS) {
         lds = bdpt_lds_scene_bytes(K.scene);
@@ -717,7 +722,7 @@ hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    dim3 grid((K.rw + 31) / 32, (K.rh + 7) / 8), block(256);
+    dim3 grid((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8), block(BDPT_BLOCK);
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
 #define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, 0, stream, K)
     if (alt) {

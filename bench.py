@@ -75,7 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per rank per step")
+    ap.add_argument("--spp", type=int, default=None,
+                    help="samples per pixel per rank per step (default: 1024 for c2, 128 for c3, 16 for c4)")
     ap.add_argument("--kernel", type=int, default=0, help="bdpt_params.kernel_variant (0 auto)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: Cornell box (the headline configuration); c3: outdoor sphere arrangement, 3840x2160 unless "
@@ -116,6 +117,8 @@ def main():
 
     if args.workload == "c3" and (args.width, args.height) == (1920, 1080):
         args.width, args.height = 3840, 2160
+    if args.spp is None:
+        args.spp = {"c2": 1024, "c3": 128, "c4": 16}[args.workload]
     W, H, SPP = args.width, args.height, args.spp
     if args.workload == "c2":
         scene, scene_name = bdpt.Scene.cornell(), "Cornell box (3 spheres + 12 triangles)"

@@ -121,6 +121,8 @@ hostlib.bdpt_host_camera_reset.argtypes = [C.c_float, _vp, _vp, _vp]
 hostlib.bdpt_host_camera_reset.restype = None
 hostlib.bdpt_host_camera_orbit.argtypes = [C.c_float, _vp, _vp, C.c_float, C.c_float, C.c_double, C.c_double, C.c_int, _vp, _vp]
 hostlib.bdpt_host_camera_orbit.restype = None
+hostlib.bdpt_host_camera_zoom.argtypes = [C.c_float, _vp, _vp, C.c_float, C.c_double, C.c_int, _vp]
+hostlib.bdpt_host_camera_zoom.restype = None
 hostlib.bdpt_host_make_seeds.argtypes = [C.c_int, C.c_int, C.c_uint32, _vp]
 hostlib.bdpt_host_make_seeds.restype = None
 hostlib.bdpt_host_write_pfm.argtypes = [C.c_char_p, _vp, C.c_int, C.c_int]
@@ -271,6 +273,15 @@ def camera_orbit(radius, orientation, direction, speed_x, speed_y, dx, dy, steps
     d = np.asarray(direction, np.float32)
     hostlib.bdpt_host_camera_orbit(radius, _ptr(o), _ptr(d), speed_x, speed_y, dx, dy, steps, _ptr(cams), _ptr(changed))
     return cams, changed[:steps]
+
+
+def camera_zoom(radius, orientation, direction, scroll_speed, dy, steps):
+    """Poses of ModelCamera after reset + `steps` middle-button drags of dy; returns cams[steps+1]."""
+    cams = np.zeros(steps + 1, camera_dtype)
+    o = np.asarray(orientation, np.float32)
+    d = np.asarray(direction, np.float32)
+    hostlib.bdpt_host_camera_zoom(radius, _ptr(o), _ptr(d), scroll_speed, dy, steps, _ptr(cams))
+    return cams
 
 
 def make_seeds(width, height, global_seed=0x5EED):

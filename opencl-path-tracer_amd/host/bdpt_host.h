@@ -181,6 +181,11 @@ void bdpt_host_camera_reset(float radius, const float orientation[3], const floa
  * isChanged() after step i. */
 void bdpt_host_camera_orbit(float radius, const float orientation[3], const float dir[3], float speed_x, float speed_y,
                             double dx, double dy, int steps, bdpt_camera *out, int *changed);
+/* reset(dir), press the middle button, then `steps` cursor moves of dy with the button held (camera.cpp:77-89:
+ * the radius shrinks by dy * scroll_speed per move and the pose is rebuilt from the eye direction); out receives
+ * steps+1 cameras */
+void bdpt_host_camera_zoom(float radius, const float orientation[3], const float dir[3], float scroll_speed, double dy,
+                           int steps, bdpt_camera *out);
 void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t *out);
 int bdpt_host_write_pfm(const char *path, const float *rgba, int width, int height);
 /* scene files: NULL on failure, with the reason in err (if err_len > 0) */

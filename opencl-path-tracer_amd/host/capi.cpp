@@ -79,6 +79,22 @@ void bdpt_host_camera_orbit(float radius, const float orientation[3], const floa
     }
 }
 
+void bdpt_host_camera_zoom(float radius, const float orientation[3], const float dir[3], float scroll_speed, double dy,
+                           int steps, bdpt_camera *out)
+{
+    ModelCamera cam;
+    cam.setScrollSpeed(scroll_speed);
+    cam.setRadius(radius);
+    cam.setOrientation({orientation[0], orientation[1], orientation[2]});
+    cam.reset({dir[0], dir[1], dir[2]});
+    out[0] = cam.getCLCamera();
+    cam.handleCursor(false, true, 0.0, 0.0);                              /* press: scrolling becomes active */
+    for (int i = 0; i < steps; i++) {
+        cam.handleCursor(false, true, 0.0, dy);
+        out[i + 1] = cam.getCLCamera();
+    }
+}
+
 void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t *out)
 {
     make_seeds(width, height, global_seed, out);

@@ -62,6 +62,15 @@ def test_orbit_keeps_radius_and_reports_change_while_held(bdpt):
     assert np.array_equal(cams[0], bdpt.camera_reset(8.0, (0, -1, 0), (1.0, 0.1, -0.1)))
 
 
+def test_middle_button_drag_changes_the_radius_only(bdpt):
+    cams = bdpt.camera_zoom(8.0, (0, -1, 0), (1.0, 0.1, -0.1), 0.05, 10.0, 6)      # camera.cpp:77-89
+    pos = cams["pos"][:, :3].astype(np.float64)
+    assert np.allclose(np.linalg.norm(pos, axis=1), 8.0 - 0.5 * np.arange(7), atol=1e-4)
+    unit = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    assert np.allclose(unit, unit[0], atol=1e-6) and np.allclose(cams["look_at"][:, :3], -unit, atol=1e-6)
+    assert np.allclose(cams["up"][:, :3], cams["up"][0, :3], atol=1e-6)
+
+
 def test_seeds_are_deterministic_and_odd(bdpt):
     a, b = bdpt.make_seeds(37, 21, 0x5EED), bdpt.make_seeds(37, 21, 0x5EED)
     assert np.array_equal(a, b) and a.size == 37 * 21 * 4

@@ -212,12 +212,18 @@ def main():
         flops = rays * f_ray + full * F_PATH_FULL + early * F_PATH_EARLY
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
         achieved = flops / avg_s / 1e12
+        note = None
+        if achieved > PEAK_FP32_VALU_TFLOPS:
+            note = ("algorithmic flops are the reference formulation's (113 per ray-triangle pair); the tiled kernel decides "
+                    "most pairs with a 25-flop bounding-sphere test, so it does less arithmetic than that")
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": hbm_traffic_bytes(args.workload, W, H, SPP),
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
             "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
         }
+        if note:
+            out["roofline"]["note"] = note
         # the same launch against the HBM roofline, to show that it is not the one that binds:
         # 16 B accumulator read + 16 B write + 4 B seed word per pixel per launch, whatever spp is
         hbm = W * H * 36 / avg_s / 1e9

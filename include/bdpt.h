@@ -102,7 +102,8 @@ enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_
  * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
  *         vertex walk them together, packed two to a register pair.
  * LDS:    the workgroup keeps the whole scene in LDS (scenes up to 24 KB of records).
- * TILED:  triangle records are staged through wave-private LDS tiles (any scene size).
+ * TILED:  per-triangle bounding spheres are staged through wave-private LDS tiles and the
+ *         triangle itself is read only for rays that come near it (any scene size).
  * AUTO:   LDS when the scene fits, else TILED. */
 enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4 };
 

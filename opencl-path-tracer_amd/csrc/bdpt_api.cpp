@@ -12,6 +12,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -45,7 +47,7 @@ struct bdpt_ctx {
     int n_planes = 0, n_triangles = 0;
 
     /* device memory */
-    float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri3 = nullptr, *d_surf = nullptr;
+    float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri_bound = nullptr, *d_surf = nullptr;
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -167,7 +169,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri3); dev_free(ctx->d_surf);
+    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_surf);
     dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
@@ -271,7 +273,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     /* the triangle array carries one zeroed record past the end: the search prefetches record i+1 */
     std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4),
         tri(((size_t)n_triangles + 1) * BDPT_TRI_F4, make_float4(0.f, 0.f, 0.f, 0.f)),
-        tri3(((size_t)n_triangles + 1) * BDPT_TRI3_F4, make_float4(0.f, 0.f, 0.f, 0.f)), surf((size_t)n_surfaces * 2);
+        bound((size_t)n_triangles + 1, make_float4(0.f, 0.f, 0.f, 0.f)), surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];
@@ -297,10 +299,16 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         q[3] = make_float4(e1.x, e1.y, e1.z, b.x);
         q[4] = make_float4(b.y, b.z, e2.x, e2.y);
         q[5] = make_float4(e2.z, ns.x, ns.y, ns.z);
-        float4 *r = &tri3[(size_t)i * BDPT_TRI3_F4];
-        r[0] = make_float4(n.x, n.y, n.z, a.x);
-        r[1] = make_float4(a.y, a.z, b.x, b.y);
-        r[2] = make_float4(b.z, c.x, c.y, c.z);
+        /* sphere around the vertices, in double and rounded outward; the factor 1.05 on the squared
+         * radius is part of the margin the device test leaves for rounding (bdpt_kernels.hip) */
+        const double mx = ((double)a.x + b.x + c.x) / 3.0, my = ((double)a.y + b.y + c.y) / 3.0, mz = ((double)a.z + b.z + c.z) / 3.0;
+        const float cx = (float)mx, cy = (float)my, cz = (float)mz;
+        double r2 = 0.0;
+        for (const clm_f3 &v : {a, b, c}) {
+            const double dx = (double)v.x - cx, dy = (double)v.y - cy, dz = (double)v.z - cz;
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        bound[i] = make_float4(cx, cy, cz, std::nextafter((float)(r2 * 1.05), INFINITY));
         tri_s[i] = t.surface;
     }
     for (int i = 0; i < n_surfaces; i++) {
@@ -311,7 +319,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_sph, sph));
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
-    HIP_TRY(ctx, dev_upload(ctx->d_tri3, tri3));
+    HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, bound));
     HIP_TRY(ctx, dev_upload(ctx->d_surf, surf));
     HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
     HIP_TRY(ctx, dev_upload(ctx->d_pln_surf, pln_s));
@@ -435,7 +443,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     std::memset(&K, 0, sizeof K);
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
-    K.scene.tri = ctx->d_tri; K.scene.tri3 = ctx->d_tri3; K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;
@@ -608,7 +616,7 @@ int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids,
     };
     bdpt_dev_scene S{};
     S.sph = ctx->d_sph; S.sph_surf = ctx->d_sph_surf; S.pln = ctx->d_pln; S.pln_surf = ctx->d_pln_surf;
-    S.tri = ctx->d_tri; S.tri3 = ctx->d_tri3; S.tri_surf = ctx->d_tri_surf; S.surf = ctx->d_surf;
+    S.tri = ctx->d_tri; S.tri_bound = ctx->d_tri_bound; S.tri_surf = ctx->d_tri_surf; S.surf = ctx->d_surf;
     S.n_spheres = (int)ctx->spheres.size(); S.n_planes = ctx->n_planes; S.n_triangles = ctx->n_triangles;
     S.n_surfaces = (int)ctx->surfaces.size();
     const size_t N = (size_t)n;

@@ -282,28 +282,6 @@ BDPT_DEV void test_triangle_scattered(Best &b, float4 q0, float4 q1, float4 q2, 
     if (i != skip) best_consider(b, p, o, 2, i);                                     /* :436, :441-448 */
 }
 
-/*
- * test_triangle_scattered on a compact record r0 = (n.xyz, a.x), r1 = (a.y, a.z, b.x, b.y),
- * r2 = (b.z, c.xyz).  The edge vectors c-a, b-c, a-b are formed here, after the culls, with the
- * subtraction the upload uses for the full record, so every later bit is the same.
- */
-BDPT_DEV void test_triangle_scattered_c(Best &b, float4 r0, float4 r1, float4 r2, int i, int skip, clm_f3 o, clm_f3 d)
-{
-    clm_f3 n = clm_make3(r0.x, r0.y, r0.z);
-    float val = clm_dot3(d, n);                                                      /* :286 */
-    clm_f3 a = clm_make3(r0.w, r1.x, r1.y);
-    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
-    if (val > 0 || t < 0) return;                                                    /* :288, :292 */
-    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
-    clm_f3 bb = clm_make3(r1.z, r1.w, r2.x);
-    clm_f3 c = clm_make3(r2.y, r2.z, r2.w);
-    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), clm_sub3(c, a)), n);              /* :298 */
-    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), clm_sub3(bb, c)), n);             /* :299 */
-    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), clm_sub3(a, bb)), n);            /* :300 */
-    if (dA < 0 || dB < 0 || dC < 0) return;                                          /* :304 */
-    if (i != skip) best_consider(b, p, o, 2, i);                                     /* :436, :441-448 */
-}
-
 /* kernel0.cl:452-473: surface id, shading normal of the winner, flip toward the ray */
 BDPT_DEV Hit finish_hit(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
 {

@@ -384,9 +384,23 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * all 64 lanes copy the tile with coalesced float4 loads (lane l copies float4
  * l, l+64, ... of the tile), then every lane walks the tile with wave-uniform
  * ds_read_b128 broadcasts, as the LDS-resident variant walks the whole scene.
- * The tiles hold compact records (three float4 per triangle, bdpt_layout.h):
- * this kernel moves every triangle through L2 and LDS once per ray, and half
- * the bytes are worth the nine subtractions that rebuild the edge vectors.
+ *
+ * What is staged is not the triangle records but one bounding sphere per
+ * triangle (bdpt_layout.h).  A ray whose line passes the sphere by more than
+ * rounding can account for cannot produce a hit point inside the triangle, so
+ * for that ray the reference's test would return "no hit" and nothing needs to
+ * be computed; only when some lane's ray comes close is the full record read
+ * (wave-uniform scalar loads) and the reference's test run, for those lanes.
+ * Every ray still meets every triangle, in index order, and every candidate
+ * that could be accepted goes through the same arithmetic as before.
+ *
+ * The margin: an accepted hit point p = o + t*d lies within a few ulp of the
+ * coordinates of the ray line and, by the three edge tests, within a few ulp of
+ * the triangle, hence within the sphere of radius R up to such terms.  The test
+ * rejects when  (1 - 1e-5) |v|^2 - (v.d)^2  >  1.05 R^2 + 1e-5 (|o|^2 + 1),  v =
+ * centre - o: the right-hand slack is some hundred times the rounding of the
+ * left-hand side (relative 1e-7 of |v|^2) and of p (relative 1e-7 of |o| + |v|),
+ * and a NaN anywhere fails the comparison, i.e. keeps the triangle.
  * Two buffers per wavefront: the global loads of tile k+1 are issued
  * before tile k is walked and written to the other buffer afterwards.
  *
@@ -397,8 +411,8 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * wavefronts of a workgroup run independently.                                 */
 /* ------------------------------------------------------------------------- */
 
-#define BDPT_TILE_TRIS 64
-#define BDPT_TILE_F4 (BDPT_TILE_TRIS * BDPT_TRI3_F4)     /* 192 float4 of compact records = 3 per lane */
+#define BDPT_TILE_TRIS 192                               /* bounding spheres per tile: 3 float4 per lane */
+#define BDPT_TILE_F4 BDPT_TILE_TRIS
 
 BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool active, clm_f3 o, clm_f3 d, int otype,
                                int oidx)
@@ -419,14 +433,15 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             if (i != skip_p) test_plane(b, q0, q1, i, o, d);
         }
     }
+    const float slack = 1.0e-5f * (clm_dot3(o, o) + 1.0f);
     const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
-    const size_t total_f4 = (size_t)(S.n_triangles + 1) * BDPT_TRI3_F4;    /* the array is padded by one record */
+    const size_t total_f4 = (size_t)S.n_triangles + 1;                     /* the array is padded by one sphere */
     float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */
     auto fetch = [&](int tile) {
         const size_t base = (size_t)tile * BDPT_TILE_F4 + lane;
-        r0 = S.tri3[base < total_f4 ? base : 0];
-        r1 = S.tri3[base + 64 < total_f4 ? base + 64 : 0];
-        r2 = S.tri3[base + 128 < total_f4 ? base + 128 : 0];
+        r0 = S.tri_bound[base < total_f4 ? base : 0];
+        r1 = S.tri_bound[base + 64 < total_f4 ? base + 64 : 0];
+        r2 = S.tri_bound[base + 128 < total_f4 ? base + 128 : 0];
     };
     if (n_tiles > 0) fetch(0);
     for (int tile = 0; tile < n_tiles; tile++) {
@@ -439,10 +454,31 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         if (active) {
             const int first = tile * BDPT_TILE_TRIS;
             const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
-            for (int j = 0; j < count; j++) {
-                const float4 *q = buf + j * BDPT_TRI3_F4;
-                test_triangle_scattered_c(b, q[0], q[1], q[2], first + j, skip_t, o, d);
+            auto near = [&](float4 s) {                                      /* see the margin above */
+                const clm_f3 v = clm_sub3(clm_make3(s.x, s.y, s.z), o);
+                const float vv = clm_dot3(v, v), vd = clm_dot3(v, d);
+                return !(__builtin_fmaf(-vd, vd, 0.99999f * vv) > s.w + slack);
+            };
+            auto full = [&](int i, bool wanted) {                            /* the reference's test, for the lanes that want it */
+                if (__builtin_amdgcn_ballot_w64(wanted) == 0) return;
+                const size_t r = (size_t)i * BDPT_TRI_F4;
+                const float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2),
+                             q3 = uload(S.tri, r + 3), q4 = uload(S.tri, r + 4);
+                const float e2z = uload(S.tri, r + 5).x;
+                if (wanted) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
+            };
+            int j = 0;
+            for (; j + 4 <= count; j += 4) {                                 /* four spheres per LDS round trip */
+                const float4 s0 = buf[j], s1 = buf[j + 1], s2 = buf[j + 2], s3 = buf[j + 3];
+                const bool n0 = near(s0), n1 = near(s1), n2 = near(s2), n3 = near(s3);
+                if (__builtin_amdgcn_ballot_w64(n0 || n1 || n2 || n3) != 0) {
+                    full(first + j, n0);
+                    full(first + j + 1, n1);
+                    full(first + j + 2, n2);
+                    full(first + j + 3, n3);
+                }
             }
+            for (; j < count; j++) full(first + j, near(buf[j]));
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -18,10 +18,9 @@
  *       q4 (b.y,  b.z,  e2.x, e2.y)   e2 = a-b
  *       q5 (e2.z, ns.x, ns.y, ns.z)   ns = normalize(cross(a-b, b-c)), the
  *                                     shading normal of kernel0.cl:467
- *   triangle, compact, 3 x float4 : (n.xyz, a.x) (a.y, a.z, b.x, b.y) (b.z, c.xyz)
- *       what the tiled kernel streams (half the bytes per triangle through L2 and LDS);
- *       the three edge vectors are one subtraction each from the vertices, the same
- *       subtraction the upload does for q1-q5
+ *   triangle bound 1 x float4 : (centre.xyz, 1.05 * radius^2) of a sphere around the three
+ *       vertices: what the tiled kernel streams; a ray that passes the sphere by more than
+ *       rounding can explain cannot hit the triangle, and only the others read the record
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
  * winning primitive only).
@@ -33,7 +32,6 @@
 #include <hip/hip_runtime.h>
 
 #define BDPT_TRI_F4 6
-#define BDPT_TRI3_F4 3
 #define BDPT_PLN_F4 2
 
 struct bdpt_dev_scene {
@@ -42,7 +40,7 @@ struct bdpt_dev_scene {
     const float4 *pln;          /* [n_planes * BDPT_PLN_F4] */
     const uint32_t *pln_surf;   /* [n_planes] */
     const float4 *tri;          /* [(n_triangles + 1) * BDPT_TRI_F4] */
-    const float4 *tri3;         /* [(n_triangles + 1) * BDPT_TRI3_F4], compact records */
+    const float4 *tri_bound;    /* [n_triangles + 1] bounding spheres */
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;

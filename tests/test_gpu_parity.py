@@ -294,6 +294,45 @@ def test_dual_variant_has_only_the_live_sampler(bdpt):
     ctx.close()
 
 
+def _mixed_soup(bdpt, n, seed):
+    """Cornell box plus n triangles of every size and shape: specks, slivers, wall-sized sheets, some far outside."""
+    rng = np.random.default_rng(seed)
+    sc = bdpt.Scene.cornell()
+    tri = np.zeros(n, bdpt.triangle_dtype)
+    size = 10.0 ** rng.uniform(-3.0, 0.6, n)
+    centre = rng.uniform(-2.8, 2.8, (n, 3))
+    centre[::17] *= 40.0                                        # far from everything, large coordinates
+    e1 = rng.standard_normal((n, 3)) * size[:, None]
+    e2 = rng.standard_normal((n, 3)) * size[:, None]
+    sliver = rng.random(n) < 0.2
+    e2[sliver] = e1[sliver] * rng.uniform(0.2, 3.0, (sliver.sum(), 1)) + rng.standard_normal((sliver.sum(), 3)) * size[sliver, None] * 1e-3
+    tri["p0"][:, :3] = centre
+    tri["p1"][:, :3] = centre + e1
+    tri["p2"][:, :3] = centre + e2
+    tri["surface"] = rng.choice([0, 1, 3, 4], n)
+    sc.triangles = np.concatenate([sc.triangles, tri])
+    return sc
+
+
+@pytest.mark.parametrize("seed,n", [(1, 700), (2, 1500), (3, 260)])
+def test_tiled_kernel_bounding_sphere_cull_never_drops_a_hit(bdpt, oracle, seed, n):
+    """The tiled kernel skips a triangle for a ray that clearly passes its bounding sphere.  Triangles from 1e-3 to 4
+    units, slivers and far-away ones, seen by eye, connection and bounce rays: every id, count and bit as the oracle."""
+    scene = _mixed_soup(bdpt, n, seed)
+    W, H = 56, 40
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_TILED)
+    for s in range(3):
+        ctx.render(2)
+        oracle.render(st, scene, scene.camera, p, 2, n_threads=8)
+        _compare(bdpt, ctx, st, "mixed soup %d launch %d:" % (seed, s))
+    ctx.close()
+    # the same scene through the kernel without the cull
+    ctx, st2, p2 = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_DIRECT)
+    ctx.render(6)
+    assert np.array_equal(ctx.read_aov(bdpt.AOV_HIT_HASH), st.hit_hash)
+    ctx.close()
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

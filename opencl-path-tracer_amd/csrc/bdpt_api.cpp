@@ -308,7 +308,18 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             const double dx = (double)v.x - cx, dy = (double)v.y - cy, dz = (double)v.z - cz;
             r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
         }
-        bound[i] = make_float4(cx, cy, cz, std::nextafter((float)(r2 * 1.05), INFINITY));
+        /* The 5 % also covers a unit normal that is off by up to 1e-4 because it comes from a cross
+         * product with cancellation.  For thinner slivers (and degenerate triangles, whose normal is
+         * NaN) the region the edge tests accept need not resemble the triangle at all: no cull then. */
+        const double ex[3][3] = {{(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z},
+                                 {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z},
+                                 {(double)c.x - b.x, (double)c.y - b.y, (double)c.z - b.z}};
+        const double crx = ex[0][1] * ex[1][2] - ex[0][2] * ex[1][1], cry = ex[0][2] * ex[1][0] - ex[0][0] * ex[1][2],
+                     crz = ex[0][0] * ex[1][1] - ex[0][1] * ex[1][0];
+        double longest2 = 0.0;
+        for (const auto &e : ex) longest2 = std::max(longest2, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        const bool well_shaped = std::sqrt(crx * crx + cry * cry + crz * crz) >= 1.0e-3 * longest2;
+        bound[i] = make_float4(cx, cy, cz, well_shaped ? std::nextafter((float)(r2 * 1.05), INFINITY) : INFINITY);
         tri_s[i] = t.surface;
     }
     for (int i = 0; i < n_surfaces; i++) {

@@ -400,7 +400,8 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * rejects when  (1 - 1e-5) |v|^2 - (v.d)^2  >  1.05 R^2 + 1e-5 (|o|^2 + 1),  v =
  * centre - o: the right-hand slack is some hundred times the rounding of the
  * left-hand side (relative 1e-7 of |v|^2) and of p (relative 1e-7 of |o| + |v|),
- * and a NaN anywhere fails the comparison, i.e. keeps the triangle.
+ * and a NaN anywhere fails the comparison, i.e. keeps the triangle.  Slivers
+ * whose computed normal is unreliable carry an infinite radius (bdpt_api.cpp).
  * Two buffers per wavefront: the global loads of tile k+1 are issued
  * before tile k is walked and written to the other buffer afterwards.
  *

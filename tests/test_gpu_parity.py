@@ -305,7 +305,8 @@ def _mixed_soup(bdpt, n, seed):
     e1 = rng.standard_normal((n, 3)) * size[:, None]
     e2 = rng.standard_normal((n, 3)) * size[:, None]
     sliver = rng.random(n) < 0.2
-    e2[sliver] = e1[sliver] * rng.uniform(0.2, 3.0, (sliver.sum(), 1)) + rng.standard_normal((sliver.sum(), 3)) * size[sliver, None] * 1e-3
+    thin = 10.0 ** rng.uniform(-7.0, -1.0, (sliver.sum(), 1))   # down to where the computed normal is noise
+    e2[sliver] = e1[sliver] * rng.uniform(0.2, 3.0, (sliver.sum(), 1)) + rng.standard_normal((sliver.sum(), 3)) * size[sliver, None] * thin
     tri["p0"][:, :3] = centre
     tri["p1"][:, :3] = centre + e1
     tri["p2"][:, :3] = centre + e2

@@ -104,7 +104,8 @@ enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_
  * LDS:    the workgroup keeps the whole scene in LDS (scenes up to 24 KB of records).
  * TILED:  per-triangle bounding spheres are staged through wave-private LDS tiles and the
  *         triangle itself is read only for rays that come near it (any scene size).
- * AUTO:   LDS when the scene fits, else TILED. */
+ * AUTO:   TILED when the scene does not fit the LDS variant or when enough of its triangles are small
+ *         against the scene for the bounding spheres to pay (estimated at upload), else LDS. */
 enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4 };
 
 typedef struct bdpt_params {
@@ -240,6 +241,8 @@ int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids,
  * For checking that device and host arithmetic agree bit for bit. */
 int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n);
 
+/* BDPT_KERNEL_* that the last launch ran (what AUTO resolved to), 0 before the first launch. */
+int bdpt_last_launch_variant(const bdpt_ctx *ctx);
 /* Device time of the most recent render launch in milliseconds (HIP events on
  * the stream the kernel ran on); waits for that launch. */
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms);

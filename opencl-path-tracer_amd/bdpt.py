@@ -94,6 +94,7 @@ lib.bdpt_num_samples.argtypes = [_vp]
 lib.bdpt_set_num_samples.argtypes = [_vp, C.c_int]
 lib.bdpt_read_accum.argtypes = [_vp, _vp]
 lib.bdpt_write_accum.argtypes = [_vp, _vp]
+lib.bdpt_last_launch_variant.argtypes = [_vp]
 lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
@@ -359,6 +360,9 @@ class Context:
         if seeds.size != self.width * self.height * 4:
             raise ValueError("seeds must hold width*height*4 words")
         self._check(lib.bdpt_upload_seeds(self._h, _ptr(seeds)))
+
+    def last_launch_variant(self):
+        return lib.bdpt_last_launch_variant(self._h)
 
     def write_accum(self, rgba):
         rgba = _as(rgba, np.float32)

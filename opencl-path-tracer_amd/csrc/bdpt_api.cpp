@@ -39,6 +39,8 @@ struct bdpt_ctx {
     int sample_offset = 0;
     int rx0 = 0, ry0 = 0, rw = 0, rh = 0;
     bool counters_on = false;
+    bool auto_tiled = false;            /* AUTO prefers the tiled kernel for this scene even if it fits LDS */
+    int last_variant = 0;
 
     /* host copies needed after upload */
     std::vector<bdpt_sphere> spheres;
@@ -335,6 +337,25 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
     HIP_TRY(ctx, dev_upload(ctx->d_pln_surf, pln_s));
     HIP_TRY(ctx, dev_upload(ctx->d_tri_surf, tri_s));
+    /* AUTO's estimate, in instructions per ray: the LDS variant runs the full test (about 64) on every
+     * triangle; the tiled variant runs the sphere test (13) on every triangle and the full test, with
+     * scalar-load operands (about 110), on those some lane of a wavefront comes near -- practically
+     * always for a triangle whose sphere is larger than an eighth of the scene, seldom for the rest. */
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        auto grow = [&](const float *p3, double r) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)p3[k] - r); hi[k] = std::max(hi[k], (double)p3[k] + r); }
+        };
+        for (int i = 0; i < n_spheres; i++) grow(spheres[i].center, spheres[i].radius);
+        for (int i = 0; i < n_triangles; i++) { grow(triangles[i].p0, 0); grow(triangles[i].p1, 0); grow(triangles[i].p2, 0); }
+        double diag2 = 0.0;
+        for (int k = 0; k < 3; k++) diag2 += hi[k] > lo[k] ? (hi[k] - lo[k]) * (hi[k] - lo[k]) : 0.0;
+        const double big2 = diag2 / 4.0 / 64.0 * 1.05;                     /* (extent / 8)^2, against the stored 1.05 R^2 */
+        long long n_big = 0;
+        for (int i = 0; i < n_triangles; i++)
+            if (!(bound[i].w < big2)) n_big++;
+        ctx->auto_tiled = n_triangles > 0 && 13LL * n_triangles + 110LL * n_big < 64LL * n_triangles;
+    }
     ctx->spheres.assign(spheres, spheres + n_spheres);
     ctx->surfaces.assign(surfaces, surfaces + n_surfaces);
     ctx->n_planes = n_planes;
@@ -521,8 +542,9 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     int variant = ctx->params.kernel_variant;
     if (variant == BDPT_KERNEL_LDS && bdpt_lds_scene_bytes(K.scene) > BDPT_LDS_SCENE_MAX)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
-    /* AUTO: keep the scene in LDS when it fits, otherwise stage it through LDS tiles */
-    if (variant == BDPT_KERNEL_AUTO) variant = bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
+    /* AUTO: see the estimate in bdpt_upload_scene */
+    if (variant == BDPT_KERNEL_AUTO)
+        variant = (bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
@@ -531,6 +553,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;
+    ctx->last_variant = variant;
     ctx->num_samples += spp;                                              /* main.cpp:131 */
     return BDPT_OK;
 }
@@ -549,6 +572,8 @@ int bdpt_render(bdpt_ctx *ctx, int spp)
     if (rc != BDPT_OK) return rc;
     return bdpt_sync(ctx);                                                /* main.cpp:121-124 */
 }
+
+int bdpt_last_launch_variant(const bdpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
 
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms)
 {

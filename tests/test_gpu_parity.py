@@ -334,6 +334,24 @@ def test_tiled_kernel_bounding_sphere_cull_never_drops_a_hit(bdpt, oracle, seed,
     ctx.close()
 
 
+def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
+    """AUTO: the Cornell box (12 wall-sized triangles) stays in LDS, also with a 12-triangle box added; a few dozen
+    small triangles tip it to the tiled kernel with its bounding-sphere test; a scene too large for LDS always."""
+    def variant_for(scene):
+        with bdpt.Context(32, 32) as ctx:
+            ctx.upload_scene(scene)
+            ctx.upload_seeds(bdpt.make_seeds(32, 32, 1))
+            ctx.set_camera(scene.camera)
+            assert ctx.last_launch_variant() == 0
+            ctx.render(1)
+            return ctx.last_launch_variant()
+    assert variant_for(bdpt.Scene.cornell()) == bdpt.KERNEL_LDS
+    assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS
+    assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS
+    assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_TILED
+    assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_TILED
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

@@ -120,7 +120,7 @@ typedef struct bdpt_params {
      * any rank can render any sample range; early-outs are ordinary samples.
      * A sample draws 5 + 4 per light-subpath vertex numbers, the first of them
      * discarded (kernel0.cl:592): no number is used by two samples while
-     * max_light_bounces <= 7. */
+     * max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler's extra draw per vertex). */
     int32_t rng_mode;
     /* Which primitive the first light-subpath rays skip.  The reference reads
      * an uninitialised id here (kernel0.cl:547-569, :675, :705); SELF = the

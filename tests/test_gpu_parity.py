@@ -352,6 +352,27 @@ def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
     assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_TILED
 
 
+def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
+    """24 random (spp, max_light_bounces, p_continue, sample offset, sampler) combinations of a class-ordered launch,
+    two launches each so that the second starts from a non-zero counter: every one bit for bit like the oracle."""
+    rng = np.random.default_rng(2024)
+    scene = bdpt.Scene.cornell()
+    W, H = 24, 16
+    for case in range(24):
+        spp = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 65, 97, 150]))
+        kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, max_light_bounces=int(rng.integers(1, 10)),
+                  p_continue=float(rng.uniform(0.05, 0.97)), sampler=int(rng.choice([0, 0, 1, 2])),
+                  kernel_variant=int(rng.choice([0, 1, 3, 4])))
+        offset = int(rng.integers(0, 5000))
+        ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=100 + case, **kw)
+        ctx.set_sample_offset(offset)
+        for launch in range(2):
+            ctx.render(spp)
+            oracle.render(st, scene, scene.camera, p, spp, sample_offset=offset, n_threads=8)
+            _compare(bdpt, ctx, st, "case %d %r spp %d offset %d launch %d:" % (case, kw, spp, offset, launch))
+        ctx.close()
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

@@ -212,7 +212,9 @@ def main():
         flops = rays * f_ray + full * F_PATH_FULL + early * F_PATH_EARLY
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
         achieved = flops / avg_s / 1e12
-        note = None
+        note = ("the flop count prices every ray of the reference formulation (counted by a launch that traces them all); "
+                "the timed launch leaves out rays and sampler evaluations whose results nothing reads "
+                "(the bounce ray of the last subpath vertex, bounce directions that roulette discards)")
         if achieved > PEAK_FP32_VALU_TFLOPS:
             note = ("algorithmic flops are the reference formulation's (113 per ray-triangle pair); the tiled kernel decides "
                     "most pairs with a 25-flop bounding-sphere test, so it does less arithmetic than that")

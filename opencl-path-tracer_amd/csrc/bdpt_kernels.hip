@@ -123,8 +123,10 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
 /* One sample (kernel0.cl:592-847).  Returns true when the reference would have
  * returned early (eye ray missed or hit a light, :645-656); col is then the raw
  * value it writes. */
-/* ALT: bounce directions from one of the samplers the reference holds but does not call (K.sampler) */
-template <bool AOV, int MODE, bool ALT>
+/* ALT: bounce directions from one of the samplers the reference holds but does not call (K.sampler).
+ * ALL_RAYS: also trace the rays whose result nothing but the ray counters and the hit-id chain can
+ * see (the bounce ray of the last vertex, kernel0.cl:793 at lti = maxL-1). */
+template <bool AOV, int MODE, bool ALT, bool ALL_RAYS>
 BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
                             uint32_t &hash, int eye_id[2], float col[4])
 {
@@ -157,24 +159,34 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     int taken = 0;
     clm_f3 incoming = clm_make3(0.0f, 0.0f, 0.0f);                        /* :659 */
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
-        clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));            /* :699 */
-        Hit vis = trace_one<MODE, true>(S, vpos, tdir, vtype, vidx);         /* :705 */
-        rays++;
-        if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
-        float contrib[4];
-        connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
-        pre *= K.p_con;                                                   /* :745 */
-        if (!K.indirect_only || lti != 0) {                               /* :752-755 */
+        if (ALL_RAYS || !K.indirect_only || lti != 0) {                   /* INDIRECT_ONLY drops the light's own connection (:752-755) */
+            clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));        /* :699 */
+            Hit vis = trace_one<MODE, true>(S, vpos, tdir, vtype, vidx);  /* :705 */
+            rays++;
+            if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
+            float contrib[4];
+            connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+            if (!K.indirect_only || lti != 0) {                           /* :752-755 */
 #pragma unroll
-            for (int k = 0; k < 4; k++) full[k] += contrib[k];
+                for (int k = 0; k < 4; k++) full[k] += contrib[k];
+            }
         }
+        pre *= K.p_con;                                                   /* :745 */
         taken++;                                                          /* :757 */
 
         clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                       /* :761 */
-        clm_f3 ldir = ALT ? sample_bounce_alt(K, w, draws, vn, incoming)
-                          : sample_cone(w, draws, vn, 3.1415f * 0.50f);   /* :767, :486 */
+        /* The bounce direction (:767) is used only if roulette (:787) lets the walk go on, and it
+         * consumes a fixed number of draws: step over them, draw the fate, and build the direction
+         * from the stepped-over numbers only when it is needed. */
+        uint32_t w_dir = w, draws_dir = 0;
+        const bool four = ALT && K.sampler == BDPT_SAMPLER_REFLECTIVE;
+        w *= four ? lcg_pow(4) : lcg_pow(3);
+        draws += four ? 4u : 3u;
         float fate = rng_float(w, draws);                                 /* :787 */
         if (fate > K.p_con) break;                                        /* :788 */
+        if (!ALL_RAYS && lti + 1 == K.max_l) break;                       /* nothing reads what the last bounce ray finds */
+        clm_f3 ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming)
+                          : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
 
         Hit nxt = trace_one<MODE, true>(S, lpos, ldir, vtype, vidx);         /* :793 */
         rays++;
@@ -240,7 +252,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                             : sample_direct<AOV, MODE, ALT>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+                                             : sample_direct<AOV, MODE, ALT, AOV || COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col);
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -487,7 +499,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
 }
 
 /* sample_direct with every early exit turned into the `alive` predicate (see above) */
-template <bool AOV, bool ALT>
+template <bool AOV, bool ALT, bool ALL_RAYS>
 BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, float xt, float yt, uint32_t &w,
                            uint32_t &draws, uint32_t &rays, uint32_t &hash, int eye_id[2], float col[4])
 {
@@ -542,10 +554,17 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
             }
             taken++;                                                      /* :757 */
             lpos = clm_mad3(0.00001f, vn, vpos);                          /* :761 */
-            ldir = ALT ? sample_bounce_alt(K, w, draws, vn, incoming)
-                       : sample_cone(w, draws, vn, 3.1415f * 0.50f);      /* :767, :486 */
+            /* as in sample_direct: the fate first, the direction only for the lanes that go on */
+            uint32_t w_dir = w, draws_dir = 0;
+            const bool four = ALT && K.sampler == BDPT_SAMPLER_REFLECTIVE;
+            w *= four ? lcg_pow(4) : lcg_pow(3);
+            draws += four ? 4u : 3u;
             const float fate = rng_float(w, draws);                       /* :787 */
             if (fate > K.p_con) alive = false;                            /* :788 */
+            if (!ALL_RAYS && lti + 1 == K.max_l) alive = false;           /* nothing reads what the last bounce ray finds */
+            if (alive)
+                ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming)
+                           : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
         }
         pre *= K.p_con;                                                   /* :745 */
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = sample_tiled<AOV, ALT>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
+        const bool early = sample_tiled<AOV, ALT, AOV || COUNT>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
         if (!live) continue;
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
         if (early && K.rng_mode == BDPT_RNG_STREAM) {

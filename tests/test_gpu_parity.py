@@ -373,6 +373,33 @@ def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("mode", ["stream", "strided_sum", "strided_mean"])
+def test_launches_without_parity_buffers_give_the_same_image_and_seeds(bdpt, oracle, variant, mode):
+    """With aov_enable = 0 the kernels leave out work only the parity buffers can see (the bounce ray of the last
+    vertex, bounce directions that roulette discards): accumulator and generator state must not notice."""
+    scene = bdpt.Scene.soup(40) if variant == 4 else bdpt.Scene.cornell()
+    W, H = 64, 48
+    kw = {"stream": {}, "strided_sum": dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM),
+          "strided_mean": dict(rng_mode=bdpt.RNG_STRIDED)}[mode]
+    for extra in ({}, dict(max_light_bounces=2, p_continue=0.95), dict(sampler=bdpt.SAMPLER_REFLECTIVE), dict(indirect_only=1)):
+        seeds = bdpt.make_seeds(W, H, 77)
+        p = bdpt.default_params(kernel_variant=variant, **kw, **extra)
+        with bdpt.Context(W, H) as ctx:
+            ctx.set_params(p)
+            ctx.upload_scene(scene)
+            ctx.upload_seeds(seeds)
+            ctx.set_camera(scene.camera)
+            ctx.render(1)
+            ctx.render(9)
+            acc, out_seeds = ctx.read_accum(), ctx.read_seeds()
+        st = oracle.State(W, H, seeds)
+        oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
+        oracle.render(st, scene, scene.camera, p, 9, n_threads=8)
+        assert np.array_equal(out_seeds, st.seeds), (mode, extra)
+        assert np.array_equal(acc.view(np.uint32), st.accum.view(np.uint32)), (mode, extra)
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

@@ -70,15 +70,63 @@ BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int
  * 2.0 (tools/valu_issue.hip).                                                  */
 /* ------------------------------------------------------------------------- */
 
-extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | n_spheres | n_planes*2] */
+extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | n_spheres | n_planes*2 | n_surfaces*2 | surface ids] */
+
+/* offsets, in float4, of the parts that follow the triangle records */
+struct LdsLayout {
+    int sph, pln, surf, ids;        /* spheres, planes, surface table, surface ids (uint32: triangles, spheres, planes) */
+};
+BDPT_DEV LdsLayout lds_layout(const bdpt_dev_scene &S)
+{
+    LdsLayout L;
+    L.sph = S.n_triangles * BDPT_TRI_F4;
+    L.pln = L.sph + S.n_spheres;
+    L.surf = L.pln + S.n_planes * BDPT_PLN_F4;
+    L.ids = L.surf + S.n_surfaces * 2;
+    return L;
+}
 
 BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
 {
-    const int n_tri = S.n_triangles * BDPT_TRI_F4, n_sph = S.n_spheres, n_pln = S.n_planes * BDPT_PLN_F4;
+    const LdsLayout L = lds_layout(S);
+    const int n_tri = S.n_triangles * BDPT_TRI_F4, n_pln = S.n_planes * BDPT_PLN_F4, n_surf = S.n_surfaces * 2;
     for (int i = threadIdx.x; i < n_tri; i += blockDim.x) bdpt_lds[i] = S.tri[i];
-    for (int i = threadIdx.x; i < n_sph; i += blockDim.x) bdpt_lds[n_tri + i] = S.sph[i];
-    for (int i = threadIdx.x; i < n_pln; i += blockDim.x) bdpt_lds[n_tri + n_sph + i] = S.pln[i];
+    for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) bdpt_lds[L.sph + i] = S.sph[i];
+    for (int i = threadIdx.x; i < n_pln; i += blockDim.x) bdpt_lds[L.pln + i] = S.pln[i];
+    for (int i = threadIdx.x; i < n_surf; i += blockDim.x) bdpt_lds[L.surf + i] = S.surf[i];
+    uint32_t *ids = (uint32_t *)(bdpt_lds + L.ids);
+    for (int i = threadIdx.x; i < S.n_triangles; i += blockDim.x) ids[i] = S.tri_surf[i];
+    for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) ids[S.n_triangles + i] = S.sph_surf[i];
+    for (int i = threadIdx.x; i < S.n_planes; i += blockDim.x) ids[S.n_triangles + S.n_spheres + i] = S.pln_surf[i];
     __syncthreads();
+}
+
+/* finish_hit (bdpt_device.h) reading the winner's record and surface id from LDS */
+BDPT_DEV Hit finish_hit_lds(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
+{
+    const LdsLayout L = lds_layout(S);
+    const uint32_t *ids = (const uint32_t *)(bdpt_lds + L.ids);
+    Hit h;
+    h.type = b.type;
+    h.idx = b.idx;
+    h.pos = b.pos;
+    h.n = clm_make3(0.0f, 0.0f, 0.0f);
+    h.surf = 0;
+    if (b.type == 0) {
+        const float4 s = bdpt_lds[L.sph + b.idx];
+        h.n = clm_normalize3(clm_sub3(clm_make3(s.x, s.y, s.z), b.pos));             /* :462 */
+        h.surf = ids[S.n_triangles + b.idx];
+    } else if (b.type == 1) {
+        const float4 q = bdpt_lds[L.pln + b.idx * BDPT_PLN_F4];
+        h.n = clm_make3(q.x, q.y, q.z);                                              /* :464 */
+        h.surf = ids[S.n_triangles + S.n_spheres + b.idx];
+    } else if (b.type == 2) {
+        const float4 q = bdpt_lds[b.idx * BDPT_TRI_F4 + 5];
+        h.n = clm_make3(q.y, q.z, q.w);                                              /* :467 */
+        h.surf = ids[b.idx];
+    }
+    if (clm_dot3(d, h.n) > 0) h.n = clm_neg3(h.n);                                   /* :471 */
+    return h;
 }
 
 template <bool SCATTERED>
@@ -89,7 +137,8 @@ BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int ot
     const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
     const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
     const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
-    const int sph0 = S.n_triangles * BDPT_TRI_F4, pln0 = sph0 + S.n_spheres;
+    const LdsLayout L = lds_layout(S);
+    const int sph0 = L.sph, pln0 = L.pln;
     for (int i = 0; i < S.n_spheres; i++) {
         const float4 s = bdpt_lds[sph0 + i];
         if (i != skip_s) test_sphere(b, s, i, o, d);
@@ -108,10 +157,17 @@ BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int ot
         if (SCATTERED) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
         else if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
     }
-    return finish_hit(S, b, d);
+    return finish_hit_lds(S, b, d);
 }
 
 enum { MODE_DIRECT = 0, MODE_DUAL = 1, MODE_LDS = 2 };
+
+/* row `i` of the surface table (2 float4 per surface: colour, emissive) */
+template <int MODE>
+BDPT_DEV float4 surface_row(const bdpt_dev_scene &S, uint32_t i)
+{
+    return MODE == MODE_LDS ? bdpt_lds[lds_layout(S).surf + (int)i] : S.surf[i];
+}
 
 /* SCATTERED: the rays of a wavefront point in unrelated directions (every ray but the eye ray) */
 template <int MODE, bool SCATTERED>
@@ -142,8 +198,8 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         col[0] = col[1] = col[2] = col[3] = 0.0f;
         return true;
     }
-    const float4 eye_diffuse = S.surf[eye.surf * 2];
-    const float4 eye_emissive = S.surf[eye.surf * 2 + 1];
+    const float4 eye_diffuse = surface_row<MODE>(S, eye.surf * 2);
+    const float4 eye_emissive = surface_row<MODE>(S, eye.surf * 2 + 1);
     if (eye_emissive.w != 0.0f) {                                         /* :645-650 */
         col[0] = eye_diffuse.x; col[1] = eye_diffuse.y; col[2] = eye_diffuse.z; col[3] = eye_diffuse.w;
         return true;
@@ -192,8 +248,8 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         rays++;
         if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
         if (nxt.type < 0) break;                                          /* :812 */
-        const float4 nd = S.surf[nxt.surf * 2];
-        const float4 ne = S.surf[nxt.surf * 2 + 1];
+        const float4 nd = surface_row<MODE>(S, nxt.surf * 2);
+        const float4 ne = surface_row<MODE>(S, nxt.surf * 2 + 1);
         if (ne.w != 0.0f) break;                                          /* :797-803 */
         acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
         if (ALT) incoming = ldir;                                         /* :831 */
@@ -757,7 +813,9 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
 
 size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S)
 {
-    return ((size_t)S.n_triangles * BDPT_TRI_F4 + (size_t)S.n_spheres + (size_t)S.n_planes * BDPT_PLN_F4) * sizeof(float4);
+    const size_t ids = ((size_t)S.n_triangles + S.n_spheres + S.n_planes + 3) / 4;   /* uint32 ids, in float4 */
+    return ((size_t)S.n_triangles * BDPT_TRI_F4 + (size_t)S.n_spheres + (size_t)S.n_planes * BDPT_PLN_F4 +
+            (size_t)S.n_surfaces * 2 + ids) * sizeof(float4);
 }
 
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)

@@ -82,6 +82,8 @@ def main():
                     help="c2: Cornell box (the headline configuration); c3: outdoor sphere arrangement, 3840x2160 unless "
                          "--width/--height are given; c4: Cornell box + 100k-triangle soup")
     ap.add_argument("--soup", type=int, default=100000)
+    ap.add_argument("--order", default="auto", choices=["auto", "index", "class", "adaptive"],
+                    help="bdpt_params.sample_order of the STRIDED + SUM launches (auto = adaptive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1; gloo only to rehearse the N > 1 code path with several ranks on one GPU")
@@ -127,8 +129,8 @@ def main():
     else:
         scene, scene_name = bdpt.Scene.soup(args.soup), "Cornell box + %d-triangle soup" % args.soup
     ctx = bdpt.Context(W, H, device=local_rank)
-    # roulette-class order pays where most samples reach the light loop; in the open c3 scene 7 of 8 eye rays leave the scene
-    order = bdpt.ORDER_INDEX if args.workload == "c3" else bdpt.ORDER_ROULETTE_CLASS
+    order = {"auto": bdpt.ORDER_AUTO, "index": bdpt.ORDER_INDEX, "class": bdpt.ORDER_ROULETTE_CLASS,
+             "adaptive": bdpt.ORDER_ADAPTIVE}[args.order]
     ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel,
                                        sample_order=order))
     ctx.upload_scene(scene)
@@ -194,7 +196,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s, %dx%d, %d spp per GPU per step, exhaustive closest hit" % (scene_name, W, H, SPP),
-            "rng_mode": "strided", "accumulate": "sum", "sample_order": "index" if order == bdpt.ORDER_INDEX else "roulette class",
+            "rng_mode": "strided", "accumulate": "sum", "sample_order": {"auto": "adaptive (roulette classes for pixels whose first eye ray reaches a surface)", "index": "index",
+                             "class": "roulette class", "adaptive": "adaptive"}[args.order],
             "split": "samples per pixel" if world > 1 else "none",
             "combine": "RCCL reduce(sum) of %dx%dx4 f32 to rank 0" % (W, H) if world > 1 else "none",
         },

@@ -84,8 +84,12 @@ enum { BDPT_ACCUM_MEAN = 0, BDPT_ACCUM_SUM = 1 };
  *                 only the order of the float additions into the accumulator differs.  Wavefronts then
  *                 trace subpaths of equal length together, which pays when most samples reach the
  *                 light loop (closed scenes) and costs when most eye rays leave the scene.
- * AUTO:           ROULETTE_CLASS when it is allowed, else INDEX. */
-enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2 };
+ * ADAPTIVE:       STRIDED + SUM only.  Per pixel: ROULETTE_CLASS if the eye ray of the launch's first
+ *                 sample index reaches a surface that is not a light, i.e. if that sample enters the
+ *                 light loop; INDEX if it ends at the eye ray (kernel0.cl:645-656), as then nearly all
+ *                 samples of the pixel do and there is nothing to order.
+ * AUTO:           ADAPTIVE when it is allowed, else INDEX. */
+enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2, BDPT_ORDER_ADAPTIVE = 3 };
 /* How a light-subpath vertex picks its bounce direction.  The live code calls brdf_lambertian
  * (kernel0.cl:767); the file holds two more samplers that nothing calls, offered here as they stand:
  * LAMBERT_CONE: brdf_lambertian, kernel0.cl:484-490 -- random_sample_cone about the normal with

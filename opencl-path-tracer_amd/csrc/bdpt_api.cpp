@@ -231,10 +231,11 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
     if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_TILED)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
-    if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ROULETTE_CLASS)
+    if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ADAPTIVE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
-    if (p->sample_order == BDPT_ORDER_ROULETTE_CLASS && !(p->rng_mode == BDPT_RNG_STRIDED && p->accum_mode == BDPT_ACCUM_SUM))
-        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS needs rng_mode STRIDED and accum_mode SUM");
+    if ((p->sample_order == BDPT_ORDER_ROULETTE_CLASS || p->sample_order == BDPT_ORDER_ADAPTIVE) &&
+        !(p->rng_mode == BDPT_RNG_STRIDED && p->accum_mode == BDPT_ACCUM_SUM))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS / ADAPTIVE needs rng_mode STRIDED and accum_mode SUM");
     if (p->sampler < BDPT_SAMPLER_LAMBERT_CONE || p->sampler > BDPT_SAMPLER_REFLECTIVE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sampler");
     if (p->sampler != BDPT_SAMPLER_LAMBERT_CONE && p->kernel_variant == BDPT_KERNEL_DUAL)
@@ -516,7 +517,9 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.falloff_c = P.falloff_c;
     K.accum_mode = P.accum_mode;
     K.sampler = P.sampler;
-    K.reorder = (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.sample_order != BDPT_ORDER_INDEX) ? 1 : 0;
+    K.reorder = 0;
+    if (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.sample_order != BDPT_ORDER_INDEX)
+        K.reorder = P.sample_order == BDPT_ORDER_ROULETTE_CLASS ? 1 : 2;   /* AUTO and ADAPTIVE: decided per pixel */
     /* (float)x * 2^-32 > p_con, the roulette test of kernel0.cl:788, as an integer test x > fate_above: the
      * conversion is monotone in x and the scaling exact, so there is one such threshold */
     {

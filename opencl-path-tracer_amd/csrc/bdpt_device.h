@@ -353,7 +353,7 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
  * same order) and changes no sample.
  */
 struct SampleCursor {
-    int cls;                /* class being collected (reorder) */
+    int cls;                /* class being collected (reorder); negative: this pixel takes its samples in index order */
     int head;               /* next sample index to examine */
     uint32_t st_head;       /* STRIDED: start state of sample head */
     uint32_t pending;       /* reorder: bit i set = sample head-1-i is of class cls and not traced yet */
@@ -420,7 +420,7 @@ static_assert(stride_inv_pow2(0) * kSampleStride == 1u, "stride inverse");
  */
 BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *seed_w, uint32_t &start)
 {
-    if (!K.reorder) {
+    if (!K.reorder || c.cls < 0) {
         if (c.head >= K.spp) return false;
         start = c.st_head;
         c.st_head *= kSampleStride;

@@ -301,6 +301,16 @@ void bdpt_direct_kernel(const bdpt_kargs K)
     float xt, yt;
     pixel_coord(K, x, y, xt, yt);
 
+    if (K.reorder == 2) {
+        /* ADAPTIVE order: does the eye ray of the launch's first sample index reach the light loop? */
+        uint32_t wp = cur.st_head, dp = 0;
+        rng_float(wp, dp);                                                /* :592 */
+        const clm_f3 dir = camera_ray(wp, dp, K, xt, yt);
+        const Hit e = trace_one<MODE == MODE_DUAL ? MODE_DIRECT : MODE, false>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0);
+        const bool early = e.type < 0 || surface_row<MODE>(K.scene, e.surf * 2 + 1).w != 0.0f;   /* :645-656 */
+        if (early) cur.cls = -1;
+    }
+
     uint32_t start;
     for (int s = 0; cursor_next(cur, K, &K.seed_w[pix], start); s++) {                    /* s counts the samples taken so far */
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
@@ -680,6 +690,18 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
     float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float xt = 0.f, yt = 0.f;
     if (inside) pixel_coord(K, x, y, xt, yt);
+
+    if (K.reorder == 2) {                                 /* ADAPTIVE order, as in bdpt_direct_kernel */
+        uint32_t wp = cur.st_head, dp = 0;
+        clm_f3 dir = clm_make3(0.f, 0.f, 1.f);
+        if (inside) {
+            rng_float(wp, dp);
+            dir = camera_ray(wp, dp, K, xt, yt);
+        }
+        const Hit e = closest_hit_tiled(K.scene, wave_lds, inside, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0);
+        const bool early = e.type < 0 || K.scene.surf[e.surf * 2 + 1].w != 0.0f;
+        if (early) cur.cls = -1;
+    }
 
     bool live = inside;                                   /* false once the pixel has no more samples in this launch */
     for (int s = 0;; s++) {                                               /* s counts the samples taken so far */

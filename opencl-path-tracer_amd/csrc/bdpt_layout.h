@@ -82,7 +82,7 @@ struct bdpt_kargs {
     int sampler;                /* BDPT_SAMPLER_* */
     /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
      * gives their light subpath (see SampleCursor in bdpt_device.h) */
-    int reorder;
+    int reorder;                /* 0 index order, 1 roulette classes, 2 roulette classes for the pixels whose first eye ray reaches a surface */
     uint32_t fate_above;        /* a roulette draw x ends the subpath iff x > fate_above */
 };
 

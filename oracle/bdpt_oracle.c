@@ -505,10 +505,17 @@ static void render_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt
     memset(&S, 0, sizeof S);
 
     /* A STRIDED + SUM call adds its samples class by class (longest roulette class first, sample
-     * index ascending within a class); every other combination takes them in index order. */
-    const int reorder = P->rng_mode == BDPT_RNG_STRIDED && P->accum_mode == BDPT_ACCUM_SUM &&
-                        P->sample_order != BDPT_ORDER_INDEX;
+     * index ascending within a class) unless sample_order says otherwise; every other combination
+     * takes them in index order. */
+    int reorder = P->rng_mode == BDPT_RNG_STRIDED && P->accum_mode == BDPT_ACCUM_SUM &&
+                  P->sample_order != BDPT_ORDER_INDEX;
     const uint32_t stride = pow_u32(48271u, 32u);
+    if (reorder && P->sample_order != BDPT_ORDER_ROULETTE_CLASS) {
+        /* ADAPTIVE (and AUTO): by classes only if the first sample index of the call enters the light loop */
+        Lane probe = L;
+        probe.w = J->seeds[sidx] * pow_u32(stride, (uint32_t)(J->sample_offset + J->num_samples));
+        reorder = !trace_sample(&probe, J, sc, x, y).early;
+    }
     int taken = 0;
     for (int cls = reorder ? P->max_light_bounces : 1; cls >= 1; cls--)
     for (int si = 0; si < J->spp; si++) {

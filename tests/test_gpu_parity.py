@@ -400,6 +400,36 @@ def test_launches_without_parity_buffers_give_the_same_image_and_seeds(bdpt, ora
         assert np.array_equal(acc.view(np.uint32), st.accum.view(np.uint32)), (mode, extra)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("which", ["cornell", "outdoor"])
+def test_adaptive_order_decides_per_pixel(bdpt, oracle, variant, which):
+    """ADAPTIVE: pixels whose first eye ray ends the sample take index order, the others class order.  Bit for bit like
+    the oracle; equal to INDEX on the first kind of pixel and to ROULETTE_CLASS on the second."""
+    scene = getattr(bdpt.Scene, which)()
+    W, H, SPP = 48, 32, 40
+    res = {}
+    for order in (bdpt.ORDER_ADAPTIVE, bdpt.ORDER_INDEX, bdpt.ORDER_ROULETTE_CLASS):
+        ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=61, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM,
+                           kernel_variant=variant, sample_order=order)
+        ctx.set_sample_offset(7)
+        ctx.render(SPP)
+        oracle.render(st, scene, scene.camera, p, SPP, sample_offset=7, n_threads=8)
+        _compare(bdpt, ctx, st, "%s order %d:" % (which, order))
+        res[order] = ctx.read_accum().view(np.uint32)
+        ctx.close()
+    # the first sample index alone, to see which pixels it ends at the eye ray
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=61, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM,
+                       kernel_variant=variant, sample_order=bdpt.ORDER_INDEX)
+    ctx.set_sample_offset(7)
+    ctx.render(1)
+    eye = ctx.read_aov(bdpt.AOV_EYE_HIT)
+    ctx.close()
+    early = (eye[..., 0] < 0) | ((eye[..., 0] == 0) & (eye[..., 1] == 0))     # missed, or saw the light (sphere 0)
+    assert early.any() and (~early).any()
+    assert np.array_equal(res[bdpt.ORDER_ADAPTIVE][early], res[bdpt.ORDER_INDEX][early])
+    assert np.array_equal(res[bdpt.ORDER_ADAPTIVE][~early], res[bdpt.ORDER_ROULETTE_CLASS][~early])
+
+
 def test_roulette_class_order_needs_strided_sum(bdpt):
     ctx = bdpt.Context(16, 16)
     for kw in (dict(), dict(rng_mode=bdpt.RNG_STRIDED), dict(accum_mode=bdpt.ACCUM_SUM)):

@@ -8,7 +8,8 @@ scene = bdpt.Scene.cornell()
 for spp in (256, 1024):
     for name, kw in (("stream/mean", {}),
                      ("strided/mean (index order)", dict(rng_mode=bdpt.RNG_STRIDED)),
-                     ("strided/sum (class order)", dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM))):
+                     ("strided/sum (class order)", dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, sample_order=bdpt.ORDER_ROULETTE_CLASS)),
+                     ("strided/sum (adaptive order)", dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM))):
         ctx = bdpt.Context(W, H)
         ctx.set_params(bdpt.default_params(**kw))
         ctx.upload_scene(scene); ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED)); ctx.set_camera(scene.camera)

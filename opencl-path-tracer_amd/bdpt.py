@@ -127,6 +127,8 @@ hostlib.bdpt_host_camera_zoom.restype = None
 hostlib.bdpt_host_make_seeds.argtypes = [C.c_int, C.c_int, C.c_uint32, _vp]
 hostlib.bdpt_host_make_seeds.restype = None
 hostlib.bdpt_host_write_pfm.argtypes = [C.c_char_p, _vp, C.c_int, C.c_int]
+hostlib.bdpt_host_scene_from_arrays.restype = _vp
+hostlib.bdpt_host_scene_from_arrays.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp]
 hostlib.bdpt_host_scene_load.restype = _vp
 hostlib.bdpt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 hostlib.bdpt_host_scene_save.argtypes = [_vp, C.c_char_p, C.c_int]
@@ -192,30 +194,18 @@ class Scene:
         return Scene._take(h)
 
     def save(self, path, binary=False):
-        """Writes the scene through the C++ host (round-trips through Scene.load)."""
-        import tempfile
-        # hand the arrays to the host library as a binary scene file, then let it write the requested form
-        hdr = np.zeros((), np.dtype([("magic", "S8"), ("n", "<u4", 4), ("view", "<f4", 4)]))
-        hdr["magic"] = b"BDPTSCN1"
-        hdr["n"] = [len(self.spheres), len(self.planes), len(self.triangles), len(self.surfaces)]
-        hdr["view"] = getattr(self, "view", (1.0, 0.1, -0.1, 8.0))
-        blob = hdr.tobytes() + self.spheres.tobytes() + self.planes.tobytes() + self.triangles.tobytes() + self.surfaces.tobytes()
-        if binary:
-            with open(path, "wb") as f:
-                f.write(blob)
-            return
-        with tempfile.NamedTemporaryFile(suffix=".bdptscn") as tmp:
-            tmp.write(blob)
-            tmp.flush()
-            err = C.create_string_buffer(512)
-            h = hostlib.bdpt_host_scene_load(os.fsencode(tmp.name), err, len(err))
-            if not h:
-                raise ValueError(err.value.decode())
-            try:
-                if hostlib.bdpt_host_scene_save(h, os.fsencode(path), 0) != 0:
-                    raise OSError("cannot write %s" % path)
-            finally:
-                hostlib.bdpt_host_scene_destroy(h)
+        """Writes the scene through the C++ host, as text or in the binary form (round-trips through Scene.load)."""
+        view = np.asarray(getattr(self, "view", (1.0, 0.1, -0.1, 8.0)), np.float32)
+        h = hostlib.bdpt_host_scene_from_arrays(_ptr(self.spheres), len(self.spheres), _ptr(self.planes), len(self.planes),
+                                                _ptr(self.triangles), len(self.triangles), _ptr(self.surfaces),
+                                                len(self.surfaces), _ptr(view))
+        if not h:
+            raise ValueError("bad scene arrays")
+        try:
+            if hostlib.bdpt_host_scene_save(h, os.fsencode(path), 1 if binary else 0) != 0:
+                raise OSError("cannot write %s" % path)
+        finally:
+            hostlib.bdpt_host_scene_destroy(h)
 
     @staticmethod
     def _take(h):

@@ -188,6 +188,10 @@ void bdpt_host_camera_zoom(float radius, const float orientation[3], const float
                            int steps, bdpt_camera *out);
 void bdpt_host_make_seeds(int width, int height, uint32_t global_seed, uint32_t *out);
 int bdpt_host_write_pfm(const char *path, const float *rgba, int width, int height);
+/* a scene from caller-held arrays (copied); view = direction xyz + radius of the default camera, or NULL */
+bdpt_host_scene *bdpt_host_scene_from_arrays(const bdpt_sphere *spheres, int n_spheres, const bdpt_plane *planes, int n_planes,
+                                            const bdpt_triangle *triangles, int n_triangles, const bdpt_surface *surfaces,
+                                            int n_surfaces, const float view[4]);
 /* scene files: NULL on failure, with the reason in err (if err_len > 0) */
 bdpt_host_scene *bdpt_host_scene_load(const char *path, char *err, int err_len);
 int bdpt_host_scene_save(const bdpt_host_scene *s, const char *path, int binary);

@@ -110,6 +110,21 @@ static void put_err(char *err, int err_len, const std::string &what)
     if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", what.c_str());
 }
 
+bdpt_host_scene *bdpt_host_scene_from_arrays(const bdpt_sphere *spheres, int n_spheres, const bdpt_plane *planes, int n_planes,
+                                            const bdpt_triangle *triangles, int n_triangles, const bdpt_surface *surfaces,
+                                            int n_surfaces, const float view[4])
+{
+    if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || n_surfaces < 0) return nullptr;
+    if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || (n_surfaces && !surfaces)) return nullptr;
+    bdpt_host_scene *s = new bdpt_host_scene();
+    s->sc.spheres.assign(spheres, spheres + n_spheres);
+    s->sc.planes.assign(planes, planes + n_planes);
+    s->sc.triangles.assign(triangles, triangles + n_triangles);
+    s->sc.surfaces.assign(surfaces, surfaces + n_surfaces);
+    if (view) { s->sc.view_dir = {view[0], view[1], view[2]}; s->sc.view_radius = view[3]; }
+    return s;
+}
+
 bdpt_host_scene *bdpt_host_scene_load(const char *path, char *err, int err_len)
 {
     bdpt_host_scene *s = new bdpt_host_scene();

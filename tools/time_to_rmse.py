@@ -1,7 +1,7 @@
 """Time-to-target RMSE (the second half of the headline metric): wall time from a camera reset until
 RMSE(accumulated image, reference) < target, sampled every `--chunk` samples per pixel.
 
-    python tools/time_to_rmse.py [--width 1920 --height 1080 --ref-spp 16384 --chunk 8 --target 0.02]
+    python tools/time_to_rmse.py [--width 1920 --height 1080 --ref-spp 16384 --chunk 64 --target 0.02]
     python -m torch.distributed.run --nproc-per-node N tools/time_to_rmse.py ...   (sample split + RCCL reduce per chunk)
 
 The reference image is a --ref-spp render with a different seed set (STREAM mode, the reference's own
@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--ref-spp", type=int, default=16384)
-ap.add_argument("--chunk", type=int, default=8, help="samples per pixel (whole job) between RMSE checks")
+ap.add_argument("--chunk", type=int, default=64, help="samples per pixel (whole job) between RMSE checks")
 ap.add_argument("--target", type=float, default=0.02)
 ap.add_argument("--max-spp", type=int, default=8192)
 a = ap.parse_args()

@@ -239,6 +239,18 @@ int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[3]);
 int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n,
                     int32_t *out_ids, float *out_pos, float *out_normal);
 
+/* bdpt_query_rays for callers that must not allocate device memory (code between the begin and end of a
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same arguments and results as bdpt_query_rays, which allocates and frees five device buffers
+ * per call; this one stages rays and results in a fixed array that is part of the library's code object
+ * (4 MiB on every GPU the library is loaded on, held until the process ends) and calls no hipMalloc /
+ * hipFree.  n may be at most BDPT_QUERY_NOALLOC_MAX_RAYS; more is BDPT_ERR_INVALID.  All contexts on one
+ * GPU share that array: calls that overlap in time on one GPU (from several threads, or several contexts
+ * on different streams) race and must be serialised by the caller. */
+#define BDPT_QUERY_NOALLOC_MAX_RAYS 65536
+int bdpt_query_rays_noalloc(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n,
+                            int32_t *out_ids, float *out_pos, float *out_normal);
+
 /* Evaluates one built-in of the numeric contract (include/bdpt_clmath.h) on the
  * GPU for n inputs of 3 doubles each: op 0 sin, 1 cos, 2 acos(float),
  * 3 acos(double), 4 sqrt, 5 a/b, 6 fma(a,b,c), 7 x of normalize(a,b,c).

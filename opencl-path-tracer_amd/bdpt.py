@@ -33,6 +33,7 @@ KERNEL_AUTO, KERNEL_DIRECT, KERNEL_DUAL, KERNEL_LDS, KERNEL_TILED = 0, 1, 2, 3, 
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
 SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE = 0, 1, 2
 AOV_EYE_HIT, AOV_HIT_HASH, AOV_RADIANCE, AOV_RNG_DRAWS, AOV_RAYS = 0, 1, 2, 3, 4
+QUERY_NOALLOC_MAX_RAYS = 65536   # BDPT_QUERY_NOALLOC_MAX_RAYS
 SCENE_CORNELL, SCENE_PLANES, SCENE_OUTDOOR, SCENE_SOUP = 0, 1, 2, 3
 
 
@@ -105,6 +106,7 @@ lib.bdpt_read_aov.argtypes = [_vp, C.c_int, _vp]
 lib.bdpt_enable_counters.argtypes = [_vp, C.c_int]
 lib.bdpt_read_counters.argtypes = [_vp, C.POINTER(C.c_uint64)]
 lib.bdpt_query_rays.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
+lib.bdpt_query_rays_noalloc.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
 lib.bdpt_clmath_eval.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int]
 lib.bdpt_last_launch_ms.argtypes = [_vp, C.POINTER(C.c_float)]
 
@@ -423,14 +425,17 @@ class Context:
         self._check(lib.bdpt_read_counters(self._h, c))
         return int(c[0]), int(c[1]), int(c[2])
 
-    def query_rays(self, rays, origin_ids):
+    def query_rays(self, rays, origin_ids, noalloc=False):
+        """Closest hits of caller-supplied rays; noalloc=True goes through bdpt_query_rays_noalloc."""
         rays = _as(rays, np.float32).reshape(-1, 6)
         origin_ids = _as(origin_ids, np.int32).reshape(-1, 2)
         n = rays.shape[0]
         ids = np.empty((n, 2), np.int32)
         pos = np.empty((n, 3), np.float32)
         nrm = np.empty((n, 3), np.float32)
-        self._check(lib.bdpt_query_rays(self._h, _ptr(rays), _ptr(origin_ids), n, _ptr(ids), _ptr(pos), _ptr(nrm)))
+        fn = lib.bdpt_query_rays_noalloc if noalloc else lib.bdpt_query_rays
+        self._check(fn(self._h, rays.ctypes.data_as(_vp), origin_ids.ctypes.data_as(_vp), n, ids.ctypes.data_as(_vp),
+                       pos.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp)))
         return ids, pos, nrm
 
     def clmath_eval(self, op, inputs):

@@ -62,6 +62,8 @@ struct bdpt_ctx {
     std::string err;
 };
 
+static_assert(BDPT_QUERY_NOALLOC_MAX_RAYS == BDPT_QUERY_STATIC_MAX, "the documented limit is the size of the staging array");
+
 static thread_local std::string g_null_ctx_error;
 
 static int fail(bdpt_ctx *ctx, int code, const std::string &msg)
@@ -674,6 +676,43 @@ int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids,
     }
     dev_free(d_rays); dev_free(d_org); dev_free(d_id); dev_free(d_pos); dev_free(d_n);
     return rc;
+}
+
+int bdpt_query_rays_noalloc(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n, int32_t *out_ids,
+                            float *out_pos, float *out_normal)
+{
+    if (!ctx || n < 0 || (n && (!rays || !origin_ids || !out_ids || !out_pos || !out_normal)))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_query_rays_noalloc: bad argument");
+    if (n > BDPT_QUERY_STATIC_MAX)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_query_rays_noalloc: at most " + std::to_string(BDPT_QUERY_STATIC_MAX) +
+                                               " rays per call (the staging array has a fixed size); use bdpt_query_rays or split the batch");
+    if (!ctx->have_scene) return fail(ctx, BDPT_ERR_STATE, "bdpt_query_rays_noalloc: no scene uploaded");
+    if (n == 0) return BDPT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *base = nullptr;
+    HIP_TRY(ctx, bdpt_query_scratch(ctx->device, &base));
+    /* fixed offsets for the full capacity, so that every part stays 256-byte aligned */
+    const size_t M = BDPT_QUERY_STATIC_MAX;
+    uint32_t *w = (uint32_t *)base;
+    float *d_rays = (float *)w;
+    int *d_org = (int *)(w + 6 * M), *d_id = (int *)(w + 8 * M);
+    float *d_pos = (float *)(w + 10 * M), *d_n = (float *)(w + 13 * M);
+    bdpt_dev_scene S{};
+    S.sph = ctx->d_sph; S.sph_surf = ctx->d_sph_surf; S.pln = ctx->d_pln; S.pln_surf = ctx->d_pln_surf;
+    S.tri = ctx->d_tri; S.tri_bound = ctx->d_tri_bound; S.tri_surf = ctx->d_tri_surf; S.surf = ctx->d_surf;
+    S.n_spheres = (int)ctx->spheres.size(); S.n_planes = ctx->n_planes; S.n_triangles = ctx->n_triangles;
+    S.n_surfaces = (int)ctx->surfaces.size();
+    const size_t N = (size_t)n;
+    /* everything on the context's stream, in order; the kernel writes all three outputs of every ray i < n,
+     * so nothing a previous (possibly larger) call left in the array can reach the caller */
+    HIP_TRY(ctx, hipMemcpyAsync(d_rays, rays, N * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_org, origin_ids, N * 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, bdpt_launch_query(S, d_rays, d_org, n, d_id, d_pos, d_n, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_ids, d_id, N * 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_pos, d_pos, N * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_normal, d_n, N * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDPT_OK;
 }
 
 int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n)

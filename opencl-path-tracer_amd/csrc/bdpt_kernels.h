@@ -26,6 +26,13 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,
                              float *out_pos, float *out_n, hipStream_t stream);
 
+/* Device address, on GPU `device` (which must be the current device), of a staging array that is part of
+ * the loaded code object: BDPT_QUERY_STATIC_MAX * 16 32-bit words, shared by every caller on that GPU.
+ * Looked up on first use per device; never allocates. */
+#define BDPT_QUERY_STATIC_MAX 65536
+#define BDPT_MAX_DEVICES 64
+hipError_t bdpt_query_scratch(int device, void **out);
+
 /* Numeric-contract built-ins evaluated on the device (see the kernel). */
 hipError_t bdpt_launch_clmath(int op, const double *in, double *out, int n, hipStream_t stream);
 

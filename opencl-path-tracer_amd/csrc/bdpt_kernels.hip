@@ -885,6 +885,37 @@ hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const i
     return hipGetLastError();
 }
 
+/* ---- device-resident staging for bdpt_query_rays_noalloc -------------------- */
+/* One array per GPU, held from the moment the library is loaded on it until the process ends.
+ * Layout, in 32-bit words, for a capacity of BDPT_QUERY_STATIC_MAX rays: rays [6*MAX] | origin ids
+ * [2*MAX] | hit ids [2*MAX] | hit positions [3*MAX] | normals [3*MAX].  The name `scratch` is only a
+ * host-side handle of the symbol; its device address is looked up once per device below and that
+ * pointer is what copies and kernels are given. */
+static __device__ __align__(256) uint32_t scratch[(size_t)BDPT_QUERY_STATIC_MAX * 16];
+
+#include <mutex>
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[BDPT_MAX_DEVICES];   /* device address of `scratch` on each GPU, null until looked up */
+
+hipError_t bdpt_query_scratch(int device, void **out)
+{
+    if (!out || device < 0 || device >= BDPT_MAX_DEVICES) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;      /* the symbol is resolved for the current device */
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 hipError_t bdpt_launch_clmath(int op, const double *in, double *out, int n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;

@@ -124,7 +124,8 @@ typedef struct bdpt_params {
      * any rank can render any sample range; early-outs are ordinary samples.
      * A sample draws 5 + 4 per light-subpath vertex numbers, the first of them
      * discarded (kernel0.cl:592): no number is used by two samples while
-     * max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler's extra draw per vertex). */
+     * max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler's extra draw per vertex);
+     * bdpt_set_params refuses STRIDED with longer subpaths. */
     int32_t rng_mode;
     /* Which primitive the first light-subpath rays skip.  The reference reads
      * an uninitialised id here (kernel0.cl:547-569, :675, :705); SELF = the
@@ -209,6 +210,11 @@ int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample);
  * render on `hip_stream` (NULL = the context's own stream), and accumulate into
  * caller-owned device memory of width*height*4 floats (NULL = internal). */
 int bdpt_set_stream(bdpt_ctx *ctx, void *hip_stream);
+/* Render on HIP's default stream (handle 0, which bdpt_set_stream reads as "the context's own"): what a
+ * caller whose own work runs on the default stream (torch without a stream context) selects, so that
+ * launches, collectives and copies are ordered by one stream instead of by the default stream's implicit
+ * synchronisation with blocking streams. */
+int bdpt_use_default_stream(bdpt_ctx *ctx);
 int bdpt_bind_accum(bdpt_ctx *ctx, void *device_rgba);
 void *bdpt_accum_device_ptr(bdpt_ctx *ctx);
 

@@ -99,6 +99,7 @@ lib.bdpt_last_launch_variant.argtypes = [_vp]
 lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
+lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
 lib.bdpt_accum_device_ptr.argtypes = [_vp]
 lib.bdpt_accum_device_ptr.restype = _vp
@@ -400,7 +401,17 @@ class Context:
         self._check(lib.bdpt_set_sample_offset(self._h, first_sample))
 
     def set_stream(self, stream_ptr):
-        self._check(lib.bdpt_set_stream(self._h, stream_ptr))
+        """Render on the HIP stream with this handle; 0 is HIP's default stream (torch's default stream)."""
+        if not stream_ptr:
+            self._check(lib.bdpt_use_default_stream(self._h))
+        else:
+            self._check(lib.bdpt_set_stream(self._h, stream_ptr))
+
+    def use_own_stream(self):
+        self._check(lib.bdpt_set_stream(self._h, None))
+
+    def clear_accum(self):
+        self.write_accum(np.zeros((self.height, self.width, 4), np.float32))
 
     def bind_accum(self, device_ptr):
         self._check(lib.bdpt_bind_accum(self._h, device_ptr))

@@ -242,6 +242,16 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sampler");
     if (p->sampler != BDPT_SAMPLER_LAMBERT_CONE && p->kernel_variant == BDPT_KERNEL_DUAL)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: the DUAL kernel variant has the LAMBERT_CONE sampler only");
+    /* STRIDED spaces the samples of a pixel 32 generator outputs apart.  A sample draws 5 + per_vertex * maxL
+     * numbers, the first of which is discarded (kernel0.cl:592, :106-109, :787): with more than 33 draws the
+     * last numbers of sample s would be the first used numbers of sample s+1. */
+    {
+        const int per_vertex = p->sampler == BDPT_SAMPLER_REFLECTIVE ? 5 : 4;
+        if (p->rng_mode == BDPT_RNG_STRIDED && 5 + per_vertex * p->max_light_bounces > 33)
+            return fail(ctx, BDPT_ERR_INVALID,
+                        "bdpt_set_params: rng_mode STRIDED needs max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler): "
+                        "longer light subpaths would reuse the random numbers of the next sample");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->params = *p;
     if (p->aov_enable) return ensure_aovs(ctx);
@@ -332,6 +342,11 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         surf[(size_t)i * 2 + 0] = make_float4(s.color[0], s.color[1], s.color[2], s.color[3]);
         surf[(size_t)i * 2 + 1] = make_float4(s.emissive[0], s.emissive[1], s.emissive[2], s.emissive[3]);
     }
+    /* the old arrays are freed one by one below: until all eight uploads have succeeded the context has no scene */
+    ctx->have_scene = false;
+    ctx->spheres.clear();
+    ctx->surfaces.clear();
+    ctx->n_planes = ctx->n_triangles = 0;
     HIP_TRY(ctx, dev_upload(ctx->d_sph, sph));
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
@@ -442,6 +457,16 @@ int bdpt_set_stream(bdpt_ctx *ctx, void *hip_stream)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->have_launch = false;
+    return BDPT_OK;
+}
+
+int bdpt_use_default_stream(bdpt_ctx *ctx)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = nullptr;                                                /* HIP's default stream */
     ctx->have_launch = false;
     return BDPT_OK;
 }

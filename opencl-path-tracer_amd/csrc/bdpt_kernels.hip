@@ -478,7 +478,10 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * rejects when  (1 - 1e-5) |v|^2 - (v.d)^2  >  1.05 R^2 + 1e-5 (|o|^2 + 1),  v =
  * centre - o: the right-hand slack is some hundred times the rounding of the
  * left-hand side (relative 1e-7 of |v|^2) and of p (relative 1e-7 of |o| + |v|),
- * and a NaN anywhere fails the comparison, i.e. keeps the triangle.  Slivers
+ * and a NaN anywhere fails the comparison, i.e. keeps the triangle.  (v.d)^2 is the squared
+ * length of v along the ray only for |d| = 1: with |d|^2 = 1 - e the left-hand side is too large by
+ * e (v.d)^2 <= e |v|^2, which the factor 1 - 1e-5 absorbs for e <= 4e-6; rays further from unit length
+ * are not culled at all.  Slivers
  * whose computed normal is unreliable carry an infinite radius (bdpt_api.cpp).
  * Two buffers per wavefront: the global loads of tile k+1 are issued
  * before tile k is walked and written to the other buffer afterwards.
@@ -512,7 +515,12 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             if (i != skip_p) test_plane(b, q0, q1, i, o, d);
         }
     }
-    const float slack = 1.0e-5f * (clm_dot3(o, o) + 1.0f);
+    /* The test below takes |d| = 1.  Directions come out of normalisations and of combinations of unit vectors,
+     * which keeps |d|^2 within a few 1e-7 of 1; a direction built around a plane normal that the scene gives
+     * with another length, or a cone sample whose tangent came out of a nearly degenerate cross product, need
+     * not be.  Such a ray skips the cull altogether (an infinite slack keeps every triangle). */
+    const float dd = clm_dot3(d, d);
+    const float slack = fabsf(dd - 1.0f) <= 4.0e-6f ? 1.0e-5f * (clm_dot3(o, o) + 1.0f) : INFINITY;
     const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
     const size_t total_f4 = (size_t)S.n_triangles + 1;                     /* the array is padded by one sphere */
     float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */

@@ -40,13 +40,16 @@ def row_band(height, world, rank, align=8):
     return y0, y1 - y0
 
 
-def render_sample_split(renderer, total_spp, world, rank):
-    """Renders this rank's share of `total_spp` samples of a fresh image. Returns the samples rendered."""
+def render_sample_split(renderer, total_spp, world, rank, wait=True):
+    """Renders this rank's share of `total_spp` samples of a fresh image. Returns the samples rendered.
+    wait=False only enqueues the launch (the reduce that follows is ordered after it by the stream)."""
     first, count = sample_range(total_spp, world, rank)
     renderer.set_sample_offset(first)
     renderer.num_samples = 0
     if count > 0:
-        renderer.render(count)
+        (renderer.render if wait else renderer.render_async)(count)
+    else:
+        renderer.clear_accum()      # fewer samples than ranks: this rank adds nothing, not what an earlier frame left
     return count
 
 

@@ -51,7 +51,68 @@ def render_case(name, scene, W, H, spp, seed, sample_offset=0, camera=None, **pk
     return st, per
 
 
+def region_seed_words(seeds, W, H, region):
+    """The generator words (word 3 of each uint4, index x*H + y) of the pixels of a region, as an (h, w) array."""
+    x0, y0, w, h = region
+    xs, ys = np.meshgrid(np.arange(x0, x0 + w), np.arange(y0, y0 + h))
+    return seeds[(xs * H + ys) * 4 + 3]
+
+
+def render_region_case(name, scene, recipe, W, H, region, spp, seed, **pkw):
+    """A region of a large frame (the frame sizes of the benchmark configurations): the per-pixel state lives in
+    the full W x H frame, only the region is rendered, and the fixture keeps the region's crop of every output
+    after each of `spp` one-sample launches.  The scene is named by its recipe (kind, soup triangles, soup seed)
+    instead of being stored: the C++ host builds it deterministically."""
+    x0, y0, w, h = region
+    seeds = bdpt.make_seeds(W, H, seed)
+    p = bdpt.default_params(aov_enable=1, **pkw)
+    st = oracle.State(W, H, seeds)
+    crop = lambda a: a[y0:y0 + h, x0:x0 + w].copy()
+    per = {k: [] for k in ("eye_hit", "hit_hash", "radiance", "accum", "rng_draws", "rays")}
+    for _ in range(spp):
+        oracle.render(st, scene, scene.camera, p, 1, region=region, n_threads=8)
+        for k, a in (("eye_hit", st.eye_hit), ("hit_hash", st.hit_hash), ("radiance", st.radiance), ("accum", st.accum),
+                     ("rng_draws", st.rng_draws), ("rays", st.rays)):
+            per[k].append(crop(a))
+    out = dict(width=np.asarray(W), height=np.asarray(H), spp=np.asarray(spp), region=np.asarray(region),
+               global_seed=np.asarray(seed), scene_kind=np.asarray(recipe[0]), n_soup=np.asarray(recipe[1]),
+               soup_seed=np.asarray(recipe[2]), camera=np.asarray(scene.camera),
+               seed_words_after=region_seed_words(st.seeds, W, H, region), **params_dict(p))
+    for k, v in per.items():
+        out["out_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    return st
+
+
+def region_cases():
+    """Regions of the 1920x1080 frame of the benchmark configurations: pixel coordinates (fp64 aspect at 1920/1080,
+    kernel0.cl:600-604) and the column-major seed index (kernel0.cl:590) at that size."""
+    cornell = bdpt.Scene.cornell()
+    W, H = 1920, 1080
+    # Cornell box at 1080p, 64x64 x 16 spp: around the light sphere, on the box's silhouette, bottom-right corner
+    st = render_region_case("region_c2_light_928_700", cornell, (bdpt.SCENE_CORNELL, 0, 0), W, H, (928, 700, 64, 64), 16, 0x5EED)
+    eye = st.eye_hit[700:764, 928:992]
+    assert ((eye[..., 0] == 0) & (eye[..., 1] == 0)).any() and (eye[..., 0] == 2).any()
+    st = render_region_case("region_c2_silhouette_1616_1000", cornell, (bdpt.SCENE_CORNELL, 0, 0), W, H, (1616, 1000, 64, 64), 16, 0x5EED)
+    eye = st.eye_hit[1000:1064, 1616:1680]
+    assert (eye[..., 0] < 0).any() and (eye[..., 0] == 2).any()
+    render_region_case("region_c2_corner_1856_1016", cornell, (bdpt.SCENE_CORNELL, 0, 0), W, H, (1856, 1016, 64, 64), 16, 0x5EED)
+    # Cornell box + 100 000-triangle soup at 1080p, 32x32 x 2 spp
+    soup = bdpt.Scene.soup(100000, 0xC0FFEE)
+    assert len(soup.triangles) == 100012
+    st = render_region_case("region_c4_soup100k_944_524", soup, (bdpt.SCENE_SOUP, 100000, 0xC0FFEE), W, H, (944, 524, 32, 32), 2, 0x5EED)
+    eye = st.eye_hit[524:556, 944:976]
+    assert (eye[..., 1] >= 12).any(), "the region must see soup triangles"
+
+
 def main():
+    if "--regions-only" not in sys.argv:
+        small_cases()
+    region_cases()
+    print("fixtures written to", HERE)
+
+
+def small_cases():
     # generator known answers
     seeds = np.array([1, 12345, 0x7FFFFFFF], np.uint32)
     fl, wd = zip(*[oracle.rng_sequence(int(s), 32) for s in seeds])
@@ -87,7 +148,6 @@ def main():
         ids.append(a.copy()); pos.append(b.copy()); nrm.append(c.copy())
     np.savez_compressed(os.path.join(HERE, "closest_hit_cornell.npz"), origins=o, dirs=d, origin_ids=org,
                         ids=np.stack(ids), pos=np.stack(pos), normals=np.stack(nrm))
-    print("fixtures written to", HERE)
 
 
 if __name__ == "__main__":

@@ -41,3 +41,42 @@ def test_closest_hit_matches_golden(bdpt):
     hit = ids[:, 0] >= 0
     assert np.array_equal(pos[hit].view(np.uint32), g["pos"][hit].view(np.uint32))
     assert np.array_equal(nrm[hit].view(np.uint32), g["normals"][hit].view(np.uint32))
+
+
+def _region_variants(case):
+    # the 100 000-triangle scene does not fit the LDS-resident kernel; AUTO must resolve to TILED there
+    return [0, 1, 4] if "soup100k" in case else [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("case,variant", [(c, v) for c in gu.REGION_CASES for v in _region_variants(c)])
+def test_region_of_the_1080p_frame_matches_golden(bdpt, case, variant):
+    """Regions of the 1920x1080 frame of the benchmark configurations (Cornell box 64x64 x 16 spp; Cornell box +
+    100 000-triangle soup 32x32 x 2 spp), one launch per sample: every output of every sample against the fixture,
+    pixels outside the region untouched."""
+    g = gu.load(case)
+    scene, p, W, H, spp, region, seed = gu.unpack_region(bdpt, g)
+    x0, y0, w, h = region
+    p.kernel_variant = variant
+    crop = lambda a: a[y0:y0 + h, x0:x0 + w]
+    with bdpt.Context(W, H) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(W, H, seed))
+        ctx.set_camera(scene.camera)
+        ctx.set_region(*region)
+        for s in range(spp):
+            ctx.render(1)
+            assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_EYE_HIT)), g["out_eye_hit"][s])
+            assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_HIT_HASH)), g["out_hit_hash"][s])
+            assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RNG_DRAWS)), g["out_rng_draws"][s])
+            assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RAYS)), g["out_rays"][s])
+            assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RADIANCE)).view(np.uint32), g["out_radiance"][s].view(np.uint32))
+            assert np.array_equal(crop(ctx.read_accum()).view(np.uint32), g["out_accum"][s].view(np.uint32))
+        if "soup100k" in case:
+            assert ctx.last_launch_variant() == (bdpt.KERNEL_DIRECT if variant == 1 else bdpt.KERNEL_TILED)
+        seeds_after = ctx.read_seeds()
+        xs, ys = np.meshgrid(np.arange(x0, x0 + w), np.arange(y0, y0 + h))
+        assert np.array_equal(seeds_after[(xs * H + ys) * 4 + 3], g["seed_words_after"])
+        acc = ctx.read_accum()
+        acc[y0:y0 + h, x0:x0 + w] = 0
+        assert not acc.any()

@@ -193,6 +193,40 @@ def test_soup_scene_parity(bdpt, oracle, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_full_size_soup_region_against_the_oracle(bdpt, oracle, variant):
+    """Cornell box + 100 000 soup triangles on the 1920x1080 frame, a 32x32 region x 2 spp, in one launch: the tiled
+    kernel over all 521 tiles (AUTO must pick it) and the plain walk, against the oracle run on the same region."""
+    scene = bdpt.Scene.soup(100000)
+    W, H = 1920, 1080
+    region = (1100, 380, 32, 32)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=0xC4, kernel_variant=variant)
+    ctx.set_region(*region)
+    ctx.render(2)
+    assert ctx.last_launch_variant() == (bdpt.KERNEL_TILED if variant == 0 else bdpt.KERNEL_DIRECT)
+    oracle.render(st, scene, scene.camera, p, 2, region=region, n_threads=16)
+    _compare(bdpt, ctx, st, "100k soup region:")
+    assert (st.eye_hit[380:412, 1100:1132, 1] >= 12).any()
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("region", [(1240, 300, 64, 64), (1856, 0, 64, 64)])
+def test_cornell_region_of_the_1080p_frame_strided_sum(bdpt, oracle, variant, region):
+    """A 64x64 region of the 1920x1080 Cornell frame x 16 spp in the benchmark's mode (STRIDED + SUM, adaptive
+    order, a sample offset as a second rank would have): pixel coordinates and seed index at the full frame size."""
+    scene = bdpt.Scene.cornell()
+    W, H = 1920, 1080
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=0x5EED, kernel_variant=variant, rng_mode=bdpt.RNG_STRIDED,
+                       accum_mode=bdpt.ACCUM_SUM)
+    ctx.set_region(*region)
+    ctx.set_sample_offset(1024)
+    ctx.render(16)
+    oracle.render(st, scene, scene.camera, p, 16, region=region, sample_offset=1024, n_threads=16)
+    _compare(bdpt, ctx, st, "1080p region %r:" % (region,))
+    ctx.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_strided_mode_and_sample_split(bdpt, oracle, variant):
     """STRIDED + SUM: two contexts rendering samples [0,6) and [6,12) add up to one context rendering [0,12)."""
@@ -363,6 +397,8 @@ def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
         kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, max_light_bounces=int(rng.integers(1, 10)),
                   p_continue=float(rng.uniform(0.05, 0.97)), sampler=int(rng.choice([0, 0, 1, 2])),
                   kernel_variant=int(rng.choice([0, 1, 3, 4])))
+        # STRIDED keeps the samples of a pixel 32 draws apart: at most 7 vertices (5 with the REFLECTIVE sampler)
+        kw["max_light_bounces"] = min(kw["max_light_bounces"], 5 if kw["sampler"] == 2 else 7)
         offset = int(rng.integers(0, 5000))
         ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=100 + case, **kw)
         ctx.set_sample_offset(offset)
@@ -428,6 +464,47 @@ def test_adaptive_order_decides_per_pixel(bdpt, oracle, variant, which):
     assert early.any() and (~early).any()
     assert np.array_equal(res[bdpt.ORDER_ADAPTIVE][early], res[bdpt.ORDER_INDEX][early])
     assert np.array_equal(res[bdpt.ORDER_ADAPTIVE][~early], res[bdpt.ORDER_ROULETTE_CLASS][~early])
+
+
+def test_strided_mode_refuses_subpaths_whose_draws_would_overlap(bdpt):
+    """STRIDED spaces samples 32 draws apart; a sample draws 5 + 4 per vertex (5 + 5 with REFLECTIVE), the first
+    discarded: 7 vertices (5 REFLECTIVE) is the most that keeps the numbers of neighbouring samples apart."""
+    ctx = bdpt.Context(16, 16)
+    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, max_light_bounces=7))
+    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, max_light_bounces=5, sampler=bdpt.SAMPLER_REFLECTIVE))
+    ctx.set_params(bdpt.default_params(max_light_bounces=40))                       # STREAM has no such limit
+    with pytest.raises(bdpt.BdptError, match="STRIDED"):
+        ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, max_light_bounces=8))
+    with pytest.raises(bdpt.BdptError, match="STRIDED"):
+        ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, max_light_bounces=6, sampler=bdpt.SAMPLER_REFLECTIVE))
+    ctx.close()
+
+
+@pytest.mark.parametrize("scale", [0.5, 2.0])
+def test_tiled_cull_with_plane_normals_that_are_not_unit_length(bdpt, oracle, scale):
+    """The reference takes plane normals as given (primitives.cpp does not normalise them).  A bounce off a plane
+    whose normal has length 0.5 or 2 starts a ray whose direction is not a unit vector; the tiled kernel's
+    bounding-sphere test must not drop hits for such rays.  Six walls as planes plus small soup triangles."""
+    rng = np.random.default_rng(5)
+    sc = bdpt.Scene.cornell_planes()
+    sc.planes = sc.planes.copy()
+    sc.planes["normal"][:, :3] *= np.float32(scale)
+    n = 400
+    tri = np.zeros(n, bdpt.triangle_dtype)
+    centre = rng.uniform(-2.7, 2.7, (n, 3))
+    tri["p0"][:, :3] = centre
+    tri["p1"][:, :3] = centre + rng.uniform(-0.15, 0.15, (n, 3))
+    tri["p2"][:, :3] = centre + rng.uniform(-0.15, 0.15, (n, 3))
+    tri["surface"] = rng.choice([0, 1, 3, 4], n)
+    sc.triangles = np.concatenate([sc.triangles, tri])
+    W, H = 56, 40
+    for variant in (bdpt.KERNEL_TILED, bdpt.KERNEL_DIRECT):
+        ctx, st, p = _pair(bdpt, oracle, sc, W, H, seed=8, kernel_variant=variant)
+        ctx.render(6)
+        oracle.render(st, sc, sc.camera, p, 6, n_threads=8)
+        _compare(bdpt, ctx, st, "normals x%g variant %d:" % (scale, variant))
+        ctx.close()
+    assert (st.rays > 6 * 3).any()          # some paths did bounce off the walls
 
 
 def test_roulette_class_order_needs_strided_sum(bdpt):

@@ -38,6 +38,11 @@ class OracleRenderer:
         self.oracle.render(self.state, self.scene, self.scene.camera, self.params, spp, region=self.region,
                            sample_offset=self.offset, n_threads=2)
 
+    render_async = render
+
+    def clear_accum(self):
+        self.state.accum[...] = 0.0
+
 
 def _worker(rank, world, port, mode, out_path):
     for p in (os.path.join(ROOT, "opencl-path-tracer_amd"), os.path.join(ROOT, "oracle")):
@@ -52,12 +57,14 @@ def _worker(rank, world, port, mode, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     scene = bdpt.Scene.cornell()
     seeds = bdpt.make_seeds(W, H, 0x5EED)
-    if mode == "samples":
+    if mode in ("samples", "samples_few"):
+        total = SPP if mode == "samples" else 1          # one sample for two ranks: rank 1 has nothing to render
         p = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
         r = OracleRenderer(bdpt, oracle, scene, p, seeds)
-        dr.render_sample_split(r, SPP, world, rank)
+        r.state.accum[...] = 7.0                          # what an earlier frame left behind
+        dr.render_sample_split(r, total, world, rank)
         t = torch.from_numpy(r.state.accum)
-        img = dr.combine_sample_split(t, SPP, dist)
+        img = dr.combine_sample_split(t, total, dist)
     else:
         p = bdpt.default_params()
         r = OracleRenderer(bdpt, oracle, scene, p, seeds)
@@ -97,6 +104,17 @@ def test_sample_split_reduce_equals_single_rank(bdpt, oracle, tmp_path):
     # the same samples summed in a different order: fp32 re-association noise only
     np.testing.assert_allclose(got, st.accum / SPP, rtol=1e-5, atol=1e-6)
     assert got.max() > 0
+
+
+@pytest.mark.timeout(300)
+def test_sample_split_with_fewer_samples_than_ranks(bdpt, oracle, tmp_path):
+    """A rank without a share contributes zeros, not what its accumulator held before."""
+    got = _run("samples_few", tmp_path)
+    scene = bdpt.Scene.cornell()
+    p = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    st = oracle.State(W, H, bdpt.make_seeds(W, H, 0x5EED))
+    oracle.render(st, scene, scene.camera, p, 1, n_threads=4)
+    assert np.array_equal(got.view(np.uint32), st.accum.view(np.uint32))
 
 
 @pytest.mark.timeout(300)

@@ -476,3 +476,19 @@ def test_render_golden(bdpt, oracle, case):
         assert np.array_equal(st.radiance.view(np.uint32), g["out_radiance"][s].view(np.uint32))
         assert np.array_equal(st.accum.view(np.uint32), g["out_accum"][s].view(np.uint32))
     assert np.array_equal(st.seeds, g["seeds_after"])
+
+
+@pytest.mark.parametrize("case", gu.REGION_CASES)
+def test_region_golden(bdpt, oracle, case):
+    """Regions of the 1920x1080 frame (Cornell 64x64 x 16 spp, 100 000-triangle soup 32x32 x 2 spp)."""
+    g = gu.load(case)
+    scene, p, W, H, spp, region, seed = gu.unpack_region(bdpt, g)
+    x0, y0, w, h = region
+    st = oracle.State(W, H, bdpt.make_seeds(W, H, seed))
+    for s in range(spp):
+        oracle.render(st, scene, scene.camera, p, 1, region=region, n_threads=8)
+    s = spp - 1
+    crop = lambda a: a[y0:y0 + h, x0:x0 + w]
+    assert np.array_equal(crop(st.eye_hit), g["out_eye_hit"][s]) and np.array_equal(crop(st.hit_hash), g["out_hit_hash"][s])
+    assert np.array_equal(crop(st.rng_draws), g["out_rng_draws"][s]) and np.array_equal(crop(st.rays), g["out_rays"][s])
+    assert np.array_equal(crop(st.accum).view(np.uint32), g["out_accum"][s].view(np.uint32))

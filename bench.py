@@ -1,46 +1,49 @@
 """BDPT throughput benchmark: Cornell box, 1920x1080, 1024 samples per pixel per step.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no launcher around it the script starts its N ranks itself (a
+`torch.distributed.run` child process, started before anything here touches the
+GPU) and passes their output through; under `torch.distributed.run` it is one of
+the ranks.
 
 One step = one pass of the hot path over one batch: every rank renders the full
 frame for its own `spp` samples of every pixel (STRIDED generator mode, rank r
 owns sample indices [r*spp, (r+1)*spp)) into a sum accumulator, then the partial
-sums are combined on rank 0 by one RCCL reduce over xGMI.  Per-GPU work is fixed
+sums are combined on rank 0 by one RCCL reduce over xGMI
+(dist_render.render_sample_split / combine_sample_split).  Per-GPU work is fixed
 as N grows (weak scaling); value = all ranks' paths / max-over-ranks time.
 One path = one pixel-sample = one execution of the reference's
 bi_directional_path_trace (/root/reference/src/kernel/kernel0.cl:571-864).
 
 Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
-FP32 vector peak with the algorithmic flop count (rays counted by the device in
-a separate, untimed launch of the same workload); `cpu_baseline` times the CPU
-oracle on this host's cores on a bounded crop of the same workload.
+FP32 vector peak; `cpu_baseline` times the CPU oracle on this host's cores on a
+bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 
-PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
 F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flops per primitive test / per ray
 F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
+F_CULL = {4: 17, 5: 30}         # flops of the cheap test in front of the triangle test: bounding sphere (TILED), slab test (LDS2)
 
 
-def hbm_traffic_bytes(workload, width, height, spp):
-    """HBM-side bytes per launch of the render kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
-    gfx950 correction for wide coalesced reads, plus WRITE_SIZE), or None when no pass was recorded for this workload
-    and image size."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def recorded(name, key):
+    """An entry of one of the committed measurement summaries under profiles/ (None if absent)."""
     try:
-        with open(path) as f:
-            rec = json.load(f).get("%s/%dx%d" % (workload, width, height))
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f).get(key)
     except (OSError, ValueError):
         return None
-    return None if rec is None else rec["fixed"] + rec["per_spp"] * spp
 
 
 def cpu_opencl_status():
@@ -68,6 +71,18 @@ def cpu_opencl_status():
     return "not run: a CPU OpenCL device exists but this build has no harness for the reference kernel"
 
 
+def start_ranks(n):
+    """N > 1 without a launcher: run this script again as N ranks under torch.distributed.run, as a child process.
+    Nothing in this process has touched the GPU at this point, and nothing will."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,17 +102,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1; gloo only to rehearse the N > 1 code path with several ranks on one GPU")
-    ap.add_argument("--stream-line", action="store_true",
-                    help="also time one launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
+    ap.add_argument("--no-stream-line", action="store_true",
+                    help="skip the extra launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
+    ap.add_argument("--dump-image", default=None, help="rank 0 saves the combined mean image of the last step (.npy)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(start_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import torch   # before the binding, so that both share one HIP runtime in this process
     import torch.distributed as dist
@@ -116,6 +132,7 @@ def main():
     import numpy as np
 
     import bdpt
+    import dist_render as dr
 
     if args.workload == "c3" and (args.width, args.height) == (1920, 1080):
         args.width, args.height = 3840, 2160
@@ -131,30 +148,32 @@ def main():
     ctx = bdpt.Context(W, H, device=local_rank)
     order = {"auto": bdpt.ORDER_AUTO, "index": bdpt.ORDER_INDEX, "class": bdpt.ORDER_ROULETTE_CLASS,
              "adaptive": bdpt.ORDER_ADAPTIVE}[args.order]
-    ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel,
-                                       sample_order=order))
+    bench_params = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel,
+                                       sample_order=order)
+    ctx.set_params(bench_params)
     ctx.upload_scene(scene)
     ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED))
     ctx.set_camera(scene.camera)
-    ctx.set_sample_offset(rank * SPP)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     ctx.bind_accum(accum.data_ptr())
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # launches, the reduce and the events below: one stream
 
-    launch_ms = []
+    launch_ms, reduce_ms = [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    image = None
 
     def step(record):
-        ctx.num_samples = 0                 # a fresh image each step; the first sample overwrites the accumulator
-        ctx.render_async(SPP)
-        if world > 1 and args.backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        elif world > 1:                     # rehearsal: gloo reduces host tensors
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                accum.copy_(host)
+        nonlocal image
+        # a fresh image each step: rank r renders samples [r*SPP, (r+1)*SPP) of world*SPP
+        dr.render_sample_split(ctx, world * SPP, world, rank, wait=False)
+        ev[0].record()
+        image = dr.combine_sample_split(accum, world * SPP, dist if world > 1 else None)
+        ev[1].record()
         if record:
             launch_ms.append(ctx.last_launch_ms())
+            if world > 1:
+                ev[1].synchronize()
+                reduce_ms.append(ev[0].elapsed_time(ev[1]))
 
     def fence():
         torch.cuda.synchronize()
@@ -174,11 +193,17 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [sum(launch_ms) / len(launch_ms)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_ms[0])
+        per_rank_ms = gathered
 
+    variant = ctx.last_launch_variant()
+    variant_name = {1: "DIRECT", 2: "DUAL", 3: "LDS", 4: "TILED", 5: "LDS2"}.get(variant, str(variant))
     paths_per_step = world * W * H * SPP
     value = paths_per_step * args.steps / elapsed / 1e6
     out = {
@@ -198,67 +223,109 @@ def main():
             "workload": "%s, %dx%d, %d spp per GPU per step, exhaustive closest hit" % (scene_name, W, H, SPP),
             "rng_mode": "strided", "accumulate": "sum", "sample_order": {"auto": "adaptive (roulette classes for pixels whose first eye ray reaches a surface)", "index": "index",
                              "class": "roulette class", "adaptive": "adaptive"}[args.order],
+            "kernel_variant": variant_name,
             "split": "samples per pixel" if world > 1 else "none",
-            "combine": "RCCL reduce(sum) of %dx%dx4 f32 to rank 0" % (W, H) if world > 1 else "none",
+            "combine": ("%s reduce(sum) of %dx%dx4 f32 to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (host tensors; rehearsal)", W, H)) if world > 1 else "none",
         },
     }
+    if world > 1:
+        out["per_rank_kernel_ms"] = [round(m, 3) for m in per_rank_ms]
+        out["reduce_ms"] = round(sum(reduce_ms) / len(reduce_ms), 3)     # rank 0: end of its launch -> combined image; includes waiting for the slowest rank
+
+    if rank == 0 and args.dump_image:
+        np.save(args.dump_image, image.cpu().numpy())
 
     if rank == 0:
-        # algorithmic work of one launch: rays and path classes counted by device atomics, untimed
+        # Work of one launch, counted by device atomics in untimed launches of the same workload:
+        #  - as the timed launch traces it (no parity buffers: rays whose result nothing reads are left out);
+        #  - as the reference formulates it (parity buffers on: every ray of kernel0.cl:571-864 is traced).
+        ctx.use_own_stream()
+        ctx.bind_accum(None)
+        ctx.set_sample_offset(0)
         ctx.enable_counters(True)
         ctx.num_samples = 0
         ctx.render(SPP)
-        rays, full, early = ctx.read_counters()
+        rays, full, early, n_cull, n_exact = ctx.read_counters()
+        ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=args.kernel,
+                                           sample_order=order, aov_enable=1))
+        ctx.set_camera(scene.camera)
+        ctx.render(SPP)
+        rays_ref, full_ref, early_ref = ctx.read_counters()[:3]
         ctx.enable_counters(False)
+        ctx.set_params(bench_params)
+        assert (full, early) == (full_ref, early_ref)
         n_s, n_p, n_t = len(scene.spheres), len(scene.planes), len(scene.triangles)
         f_ray = F_SPHERE * n_s + F_PLANE * n_p + F_TRIANGLE * n_t + F_RAY_FIXED
-        flops = rays * f_ray + full * F_PATH_FULL + early * F_PATH_EARLY
+        f_paths = full * F_PATH_FULL + early * F_PATH_EARLY
+        flops_ref = rays_ref * f_ray + f_paths
+        if variant in F_CULL:
+            # a cheap conservative test decides most (ray, triangle) pairs; price the tests that were run
+            flops = rays * (F_SPHERE * n_s + F_PLANE * n_p + F_RAY_FIXED) + n_cull * F_CULL[variant] + n_exact * F_TRIANGLE + f_paths
+        else:
+            flops = rays * f_ray + f_paths
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
         achieved = flops / avg_s / 1e12
-        note = ("the flop count prices every ray of the reference formulation (counted by a launch that traces them all); "
-                "the timed launch leaves out rays and sampler evaluations whose results nothing reads "
-                "(the bounce ray of the last subpath vertex, bounce directions that roulette discards)")
-        if achieved > PEAK_FP32_VALU_TFLOPS:
-            note = ("algorithmic flops are the reference formulation's (113 per ray-triangle pair); the tiled kernel decides "
-                    "most pairs with a 25-flop bounding-sphere test, so it does less arithmetic than that")
+        traffic = recorded("hbm_traffic.json", "%s/%dx%d" % (args.workload, W, H))
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": hbm_traffic_bytes(args.workload, W, H, SPP),
-            "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "rays_per_launch": rays,
-            "paths_full": full, "paths_early": early, "flops_per_ray": f_ray,
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+            "frac_reference_formulation": round(flops_ref / avg_s / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
+            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP,
+            "traffic_source": None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run"),
+            "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "flops_per_launch_reference_formulation": flops_ref,
+            "rays_traced": rays, "rays_reference_formulation": rays_ref, "paths_full": full, "paths_early": early,
+            "flops_per_ray": f_ray, "cull_tests": n_cull, "exact_triangle_tests_after_cull": n_exact,
+            "note": ("frac prices the tests the timed launch ran (rays traced x per-primitive flops of the reference's tests; for "
+                     "kernels with a cheap conservative test in front of the triangle test: cull tests x %s + triangle tests "
+                     "actually run x 113); frac_reference_formulation prices every ray and every (ray, primitive) pair of "
+                     "the reference's formulation, which a kernel that culls does not execute -- it may exceed 1" % F_CULL.get(variant, "n/a")),
         }
-        if note:
-            out["roofline"]["note"] = note
+        executed = recorded("pmc_summary.json", "%s/%s" % (args.workload, variant_name))
+        if executed is not None:
+            out["roofline"]["executed"] = executed       # hardware view of the same launch, from committed PMC passes
         # the same launch against the HBM roofline, to show that it is not the one that binds:
         # 16 B accumulator read + 16 B write + 4 B seed word per pixel per launch, whatever spp is
         hbm = W * H * 36 / avg_s / 1e9
         out["roofline_hbm"] = {"bound": "hbm", "achieved": round(hbm, 3), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(hbm / 8000.0, 6), "traffic": out["roofline"]["traffic"],
                                "algorithmic_bytes": W * H * 36}
-        # the same frame with the reference's sequential generator and running-mean blend (one launch, untimed above):
-        # samples are taken in index order there, so the wavefronts pay for roulette divergence
-        if args.stream_line:
+        # the same frame with the reference's sequential generator and running-mean blend (one launch, outside the timed
+        # region): samples are taken in index order there, so the wavefronts pay for roulette divergence
+        if not args.no_stream_line and world == 1:
             ctx.set_params(bdpt.default_params(kernel_variant=args.kernel))
+            ctx.set_camera(scene.camera)
+            ctx.render(SPP)
             ctx.num_samples = 0
             ctx.render(SPP)
             out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
-                                  "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2)}
+                                  "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
+                                  "what": "rng_mode STREAM + accum_mode MEAN: the reference's own generator and running mean, one launch"}
+            ctx.set_params(bench_params)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_bind as oracle   # the checker, timed here as the CPU baseline
 
         threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-        cw, ch, cspp = min(W, 640), min(H, 360), 512
-        region = ((W - cw) // 2, (H - ch) // 2, cw, ch)
+        # a sample with the frame's own mix of paths: a 6 x 4 grid of blocks spread evenly over the frame
+        gx, gy, bw, bh, cspp = 6, 4, min(W // 6, 80), min(H // 4, 60), 1024
         st = oracle.State(W, H, bdpt.make_seeds(W, H, 0x5EED))
         p = bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+        if args.workload == "c4":
+            gx, gy, bw, bh, cspp = 4, 3, 16, 8, 1
         t0 = time.perf_counter()
-        oracle.render(st, scene, scene.camera, p, cspp, region=region, n_threads=threads)
+        for j in range(gy):
+            for i in range(gx):
+                x0 = (W // gx) * i + (W // gx - bw) // 2
+                y0 = (H // gy) * j + (H // gy - bh) // 2
+                st.num_samples = 0
+                oracle.render(st, scene, scene.camera, p, cspp, region=(x0, y0, bw, bh), n_threads=threads)
         cpu_s = time.perf_counter() - t0
+        n_paths = gx * gy * bw * bh * cspp
         out["cpu_baseline"] = {
-            "value": round(cw * ch * cspp / cpu_s / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": "centre %dx%d crop of the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s" % (cw, ch, W, H, cspp, cpu_s),
+            "value": round(n_paths / cpu_s / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": "%d x %d blocks of %dx%d pixels spread evenly over the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s"
+                      % (gx, gy, bw, bh, W, H, cspp, cpu_s),
             "reference_opencl_on_cpu": cpu_opencl_status(),
         }
 

@@ -205,6 +205,12 @@ int bdpt_write_accum(bdpt_ctx *ctx, const float *rgba);
  * sample index this context renders after a camera reset (spp split). */
 int bdpt_set_region(bdpt_ctx *ctx, int x0, int y0, int w, int h);
 int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample);
+/* Interleaved tile split, for balance: the region is cut into tiles of tile_w x tile_h pixels (multiples of
+ * 16 and 8; edge tiles are clipped), numbered row by row from the region's top-left corner, and render calls
+ * touch only the tiles whose number is `phase` modulo `stride` (rank r of N passes stride N, phase r).  Eye
+ * rays that leave the scene end a path after one ray (kernel0.cl:652-656), so contiguous bands of a frame
+ * cost very different amounts; tiles dealt round-robin even that out.  stride 1, phase 0: the whole region. */
+int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, int phase);
 
 /* Interop with a caller that owns device memory and streams (torch):
  * render on `hip_stream` (NULL = the context's own stream), and accumulate into
@@ -229,12 +235,19 @@ enum {
 };
 int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out);
 
-/* Work counters of the most recent render call that was made with
- * counting on: out[0] closest-hit queries, out[1] samples that reached the
- * light loop, out[2] samples that ended at the eye ray.  Counting adds device
- * atomics, so it is off unless enabled here. */
+/* Work counters of the most recent render call that was made with counting on:
+ * out[0] closest-hit queries traced, out[1] samples that reached the light loop,
+ * out[2] samples that ended at the eye ray; for the kernel variants that put a
+ * cheap conservative test in front of the triangle test, out[3] (ray, triangle)
+ * pairs given that cheap test and out[4] pairs that then went through the
+ * reference's triangle test (both 0 for the variants that test every pair in full).
+ * A launch without parity buffers (aov_enable = 0) leaves out the rays whose
+ * result nothing reads, and out[0] counts what it traced; with aov_enable = 1
+ * every ray of the reference's formulation is traced and counted.  Counting adds
+ * device atomics, so it is off unless enabled here. */
+#define BDPT_N_COUNTERS 5
 int bdpt_enable_counters(bdpt_ctx *ctx, int on);
-int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[3]);
+int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[BDPT_N_COUNTERS]);
 
 /* Closest hit (ray_intersect, kernel0.cl:365-478) of n caller-supplied rays
  * against the uploaded scene, on the GPU.  rays: 6 floats per ray (origin xyz,

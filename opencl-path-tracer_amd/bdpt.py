@@ -98,6 +98,7 @@ lib.bdpt_write_accum.argtypes = [_vp, _vp]
 lib.bdpt_last_launch_variant.argtypes = [_vp]
 lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
+lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
 lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
@@ -397,6 +398,9 @@ class Context:
     def set_region(self, x0, y0, w, h):
         self._check(lib.bdpt_set_region(self._h, x0, y0, w, h))
 
+    def set_tile_interleave(self, tile_w, tile_h, stride, phase):
+        self._check(lib.bdpt_set_tile_interleave(self._h, tile_w, tile_h, stride, phase))
+
     def set_sample_offset(self, first_sample):
         self._check(lib.bdpt_set_sample_offset(self._h, first_sample))
 
@@ -432,9 +436,11 @@ class Context:
         self._check(lib.bdpt_enable_counters(self._h, 1 if on else 0))
 
     def read_counters(self):
-        c = (C.c_uint64 * 3)()
+        """(rays traced, samples that reached the light loop, samples that ended at the eye ray, cheap cull tests,
+        exact triangle tests that followed a cull test) of the last counted launch."""
+        c = (C.c_uint64 * 5)()
         self._check(lib.bdpt_read_counters(self._h, c))
-        return int(c[0]), int(c[1]), int(c[2])
+        return tuple(int(v) for v in c)
 
     def query_rays(self, rays, origin_ids, noalloc=False):
         """Closest hits of caller-supplied rays; noalloc=True goes through bdpt_query_rays_noalloc."""

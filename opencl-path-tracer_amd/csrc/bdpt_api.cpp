@@ -38,6 +38,7 @@ struct bdpt_ctx {
     int num_samples = 0;
     int sample_offset = 0;
     int rx0 = 0, ry0 = 0, rw = 0, rh = 0;
+    int tile_w = 0, tile_h = 0, tile_stride = 1, tile_phase = 0;
     bool counters_on = false;
     bool auto_tiled = false;            /* AUTO prefers the tiled kernel for this scene even if it fits LDS */
     int last_variant = 0;
@@ -162,8 +163,8 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if ((e = hipMemset(ctx->d_accum_own, 0, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMemset accum");
     ctx->d_accum = ctx->d_accum_own;
     if ((e = hipMalloc((void **)&ctx->d_seed_w, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc seeds");
-    if ((e = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counters");
-    if ((e = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset counters");
+    if ((e = hipMalloc((void **)&ctx->d_counters, BDPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counters");
+    if ((e = hipMemset(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset counters");
     *out = ctx;
     return BDPT_OK;
 }
@@ -444,6 +445,21 @@ int bdpt_set_region(bdpt_ctx *ctx, int x0, int y0, int w, int h)
     return BDPT_OK;
 }
 
+int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, int phase)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    if (stride <= 1) {
+        if (stride < 1 || phase != 0) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_tile_interleave: stride must be >= 1 and phase 0 when stride is 1");
+        ctx->tile_stride = 1; ctx->tile_phase = 0;
+        return BDPT_OK;
+    }
+    if (tile_w < 16 || tile_w % 16 || tile_h < 8 || tile_h % 8)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_tile_interleave: tile width must be a multiple of 16 pixels, tile height of 8");
+    if (phase < 0 || phase >= stride) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_tile_interleave: phase must be in [0, stride)");
+    ctx->tile_w = tile_w; ctx->tile_h = tile_h; ctx->tile_stride = stride; ctx->tile_phase = phase;
+    return BDPT_OK;
+}
+
 int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample)
 {
     if (!ctx || first_sample < 0) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_sample_offset: bad argument");
@@ -516,6 +532,9 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.counters = ctx->d_counters;
     K.width = ctx->width; K.height = ctx->height;
     K.rx0 = ctx->rx0; K.ry0 = ctx->ry0; K.rw = ctx->rw; K.rh = ctx->rh;
+    K.tile_stride = ctx->tile_stride; K.tile_phase = ctx->tile_phase;
+    K.tile_w = ctx->tile_w; K.tile_h = ctx->tile_h;
+    K.tiles_x = ctx->tile_stride > 1 ? (ctx->rw + ctx->tile_w - 1) / ctx->tile_w : 1;
     K.num_samples = ctx->num_samples;
     K.spp = spp;
     K.first_sample = (uint32_t)(ctx->sample_offset + ctx->num_samples);
@@ -575,7 +594,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     /* AUTO: see the estimate in bdpt_upload_scene */
     if (variant == BDPT_KERNEL_AUTO)
         variant = (bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
-    if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
@@ -654,14 +673,14 @@ int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out)
     return BDPT_OK;
 }
 
-int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[3])
+int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[BDPT_N_COUNTERS])
 {
     if (!ctx || !out) return fail(ctx, BDPT_ERR_INVALID, "bdpt_read_counters: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long c[3];
+    unsigned long long c[BDPT_N_COUNTERS];
     HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    for (int i = 0; i < BDPT_N_COUNTERS; i++) out[i] = c[i];
     return BDPT_OK;
 }
 

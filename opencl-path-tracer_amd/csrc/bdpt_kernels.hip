@@ -26,6 +26,25 @@
 
 namespace bdpt {
 
+/* Pixel of this lane.  Whole region: a 2-D grid of workgroups, 16x8 pixels each.  Interleaved tile split: a 1-D
+ * grid that enumerates, tile after tile, the workgroups of the tiles this launch owns. */
+BDPT_DEV void lane_pixel(const bdpt_kargs &K, int &x, int &y)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, ox = K.rx0, oy = K.ry0;
+    if (K.tile_stride > 1) {
+        const int bw = K.tile_w / BDPT_BLOCK_W, per_tile = bw * (K.tile_h / 8);
+        const int owned = (int)blockIdx.x / per_tile, local = (int)blockIdx.x % per_tile;
+        const int t = K.tile_phase + owned * K.tile_stride;
+        ox += (t % K.tiles_x) * K.tile_w;
+        oy += (t / K.tiles_x) * K.tile_h;
+        bx = local % bw;
+        by = local / bw;
+    }
+    x = ox + bx * BDPT_BLOCK_W + wv * 8 + (lane & 7);
+    y = oy + by * 8 + (lane >> 3);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Direct variant: every lane walks the primitive arrays itself.  All lanes of
  * a wavefront read the same record at the same time, so the reads are
@@ -279,9 +298,8 @@ __global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = K.rx0 + (int)blockIdx.x * BDPT_BLOCK_W + wv * 8 + (lane & 7);
-    const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
+    int x, y;
+    lane_pixel(K, x, y);
     if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
     const size_t pix = (size_t)y * K.width + x;
 
@@ -309,6 +327,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         const Hit e = trace_one<MODE == MODE_DUAL ? MODE_DIRECT : MODE, false>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0);
         const bool early = e.type < 0 || surface_row<MODE>(K.scene, e.surf * 2 + 1).w != 0.0f;   /* :645-656 */
         if (early) cur.cls = -1;
+        if (COUNT && !AOV) c_rays++;                 /* a ray this launch form traces on top of the samples' own */
     }
 
     uint32_t start;
@@ -318,7 +337,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                             : sample_direct<AOV, MODE, ALT, AOV || COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col);
+                                             : sample_direct<AOV, MODE, ALT, AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -496,8 +515,10 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
 #define BDPT_TILE_TRIS 192                               /* bounding spheres per tile: 3 float4 per lane */
 #define BDPT_TILE_F4 BDPT_TILE_TRIS
 
+/* COUNT: also count, per lane, the bounding-sphere tests made and the triangle tests that followed them */
+template <bool COUNT = false>
 BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool active, clm_f3 o, clm_f3 d, int otype,
-                               int oidx)
+                               int oidx, unsigned long long *n_cull = nullptr, unsigned long long *n_exact = nullptr)
 {
     Best b;
     best_init(b);
@@ -541,6 +562,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         if (active) {
             const int first = tile * BDPT_TILE_TRIS;
             const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
+            if (COUNT) *n_cull += (unsigned long long)count;
             auto near = [&](float4 s) {                                      /* see the margin above */
                 const clm_f3 v = clm_sub3(clm_make3(s.x, s.y, s.z), o);
                 const float vv = clm_dot3(v, v), vd = clm_dot3(v, d);
@@ -553,6 +575,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
                              q3 = uload(S.tri, r + 3), q4 = uload(S.tri, r + 4);
                 const float e2z = uload(S.tri, r + 5).x;
                 if (wanted) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
+                if (COUNT && wanted) ++*n_exact;
             };
             int j = 0;
             for (; j + 4 <= count; j += 4) {                                 /* four spheres per LDS round trip */
@@ -573,9 +596,10 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
 }
 
 /* sample_direct with every early exit turned into the `alive` predicate (see above) */
-template <bool AOV, bool ALT, bool ALL_RAYS>
+template <bool AOV, bool ALT, bool ALL_RAYS, bool COUNT>
 BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, float xt, float yt, uint32_t &w,
-                           uint32_t &draws, uint32_t &rays, uint32_t &hash, int eye_id[2], float col[4])
+                           uint32_t &draws, uint32_t &rays, uint32_t &hash, int eye_id[2], float col[4],
+                           unsigned long long *n_cull, unsigned long long *n_exact)
 {
     const bdpt_dev_scene &S = K.scene;
     clm_f3 dir = clm_make3(0.f, 0.f, 1.f), eye_pos = dir;
@@ -584,7 +608,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
         dir = camera_ray(w, draws, K, xt, yt);
         eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));                 /* :632 */
     }
-    Hit eye = closest_hit_tiled(S, wave_lds, live, eye_pos, dir, 4, 0);   /* :634 */
+    Hit eye = closest_hit_tiled<COUNT>(S, wave_lds, live, eye_pos, dir, 4, 0, n_cull, n_exact);   /* :634 */
     bool early = false;
     float4 eye_diffuse = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -615,7 +639,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;               /* wave-uniform */
         clm_f3 tdir = clm_make3(0.f, 0.f, 1.f);
         if (alive) tdir = clm_normalize3(clm_sub3(eye.pos, vpos));        /* :699 */
-        Hit vis = closest_hit_tiled(S, wave_lds, alive, vpos, tdir, vtype, vidx);   /* :705 */
+        Hit vis = closest_hit_tiled<COUNT>(S, wave_lds, alive, vpos, tdir, vtype, vidx, n_cull, n_exact);   /* :705 */
         clm_f3 lpos = vpos, ldir = tdir;
         if (alive) {
             rays++;
@@ -642,7 +666,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
         }
         pre *= K.p_con;                                                   /* :745 */
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-        Hit nxt = closest_hit_tiled(S, wave_lds, alive, lpos, ldir, vtype, vidx);   /* :793 */
+        Hit nxt = closest_hit_tiled<COUNT>(S, wave_lds, alive, lpos, ldir, vtype, vidx, n_cull, n_exact);   /* :793 */
         if (alive) {
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
@@ -677,10 +701,9 @@ template <bool AOV, bool COUNT, bool ALT>
 __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs K)
 {
     __shared__ float4 tiles[BDPT_BLOCK / 64][2 * BDPT_TILE_F4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4 *wave_lds = tiles[wv];
-    const int x = K.rx0 + (int)blockIdx.x * BDPT_BLOCK_W + wv * 8 + (lane & 7);
-    const int y = K.ry0 + (int)blockIdx.y * 8 + (lane >> 3);
+    float4 *wave_lds = tiles[threadIdx.x >> 6];
+    int x, y;
+    lane_pixel(K, x, y);
     const bool inside = x < K.rx0 + K.rw && y < K.ry0 + K.rh;             /* lanes outside still help copy tiles */
     const size_t pix = inside ? (size_t)y * K.width + x : 0;
 
@@ -693,7 +716,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV && inside) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
-    unsigned long long c_rays = 0, c_full = 0, c_early = 0;
+    unsigned long long c_rays = 0, c_full = 0, c_early = 0, c_cull = 0, c_exact = 0;
     int eye_id[2] = {-1, -1};
     float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float xt = 0.f, yt = 0.f;
@@ -706,9 +729,10 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
             rng_float(wp, dp);
             dir = camera_ray(wp, dp, K, xt, yt);
         }
-        const Hit e = closest_hit_tiled(K.scene, wave_lds, inside, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0);
+        const Hit e = closest_hit_tiled<COUNT>(K.scene, wave_lds, inside, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0, &c_cull, &c_exact);
         const bool early = e.type < 0 || K.scene.surf[e.surf * 2 + 1].w != 0.0f;
         if (early) cur.cls = -1;
+        if (COUNT && !AOV && inside) c_rays++;
     }
 
     bool live = inside;                                   /* false once the pixel has no more samples in this launch */
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = sample_tiled<AOV, ALT, AOV || COUNT>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col);
+        const bool early = sample_tiled<AOV, ALT, AOV, COUNT>(K, wave_lds, live, xt, yt, w, draws, rays, hash, eye_id, col, &c_cull, &c_exact);
         if (!live) continue;
         if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -765,6 +789,8 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
         atomicAdd(&K.counters[0], c_rays);
         atomicAdd(&K.counters[1], c_full);
         atomicAdd(&K.counters[2], c_early);
+        atomicAdd(&K.counters[3], c_cull);
+        atomicAdd(&K.counters[4], c_exact);
     }
 }
 
@@ -812,11 +838,21 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 
 /* ---- launch wrappers ------------------------------------------------------ */
 
+/* grid of a per-pixel launch: see lane_pixel */
+static dim3 pixel_grid(const bdpt_kargs &K)
+{
+    if (K.tile_stride <= 1) return dim3((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8);
+    const int tiles_y = (K.rh + K.tile_h - 1) / K.tile_h, n_tiles = K.tiles_x * tiles_y;
+    const int owned = n_tiles > K.tile_phase ? (n_tiles - K.tile_phase + K.tile_stride - 1) / K.tile_stride : 0;
+    return dim3((unsigned)owned * (K.tile_w / BDPT_BLOCK_W) * (K.tile_h / 8), 1);
+}
+
 template <int MODE>
 static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    dim3 grid((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8), block(BDPT_BLOCK);
+    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    if (grid.x == 0) return hipSuccess;                  /* this share owns no tile of the region */
     size_t lds = 0;
     if (MODE == bdpt::MODE_LDS) {
         lds = bdpt_lds_scene_bytes(K.scene);
@@ -866,7 +902,8 @@ hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    dim3 grid((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8), block(BDPT_BLOCK);
+    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    if (grid.x == 0) return hipSuccess;
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
 #define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, 0, stream, K)
     if (alt) {

@@ -56,9 +56,13 @@ struct bdpt_kargs {
     float4 *aov_radiance;
     uint32_t *aov_rng_draws;
     uint32_t *aov_rays;
-    unsigned long long *counters;   /* [3] rays, light-loop samples, eye-only samples */
+    unsigned long long *counters;   /* [5] rays, light-loop samples, eye-only samples, cull tests, exact triangle tests after a cull test */
     int width, height;
     int rx0, ry0, rw, rh;       /* region rendered by this launch */
+    /* Interleaved tile split: the region is cut into tiles of tile_w x tile_h pixels, numbered row by row
+     * (tiles_x per row), and this launch renders the tiles whose number is tile_phase modulo tile_stride.
+     * tile_stride <= 1: the whole region.  tile_w is a multiple of the workgroup's 16 pixels, tile_h of 8. */
+    int tile_w, tile_h, tiles_x, tile_stride, tile_phase;
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;
     uint32_t first_sample;      /* STRIDED: sample_offset + num_samples */

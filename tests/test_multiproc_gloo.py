@@ -18,13 +18,16 @@ class OracleRenderer:
     def __init__(self, bdpt, oracle, scene, params, seeds):
         self.bdpt, self.oracle, self.scene, self.params = bdpt, oracle, scene, params
         self.state = oracle.State(W, H, seeds)
-        self.offset, self.region = 0, None
+        self.offset, self.region, self.tiles = 0, None, (0, 0, 1, 0)
 
     def set_sample_offset(self, first):
         self.offset = first
 
     def set_region(self, x0, y0, w, h):
         self.region = (x0, y0, w, h)
+
+    def set_tile_interleave(self, tile_w, tile_h, stride, phase):
+        self.tiles = (tile_w, tile_h, stride, phase)
 
     @property
     def num_samples(self):
@@ -35,8 +38,21 @@ class OracleRenderer:
         self.state.num_samples = n
 
     def render(self, spp):
-        self.oracle.render(self.state, self.scene, self.scene.camera, self.params, spp, region=self.region,
-                           sample_offset=self.offset, n_threads=2)
+        tw, th, stride, phase = self.tiles
+        if stride <= 1:
+            self.oracle.render(self.state, self.scene, self.scene.camera, self.params, spp, region=self.region,
+                               sample_offset=self.offset, n_threads=2)
+            return
+        # the oracle renders rectangles: one call per owned tile, each from the same sample counter
+        x0, y0, w, h = self.region if self.region is not None else (0, 0, W, H)
+        tiles_x = (w + tw - 1) // tw
+        n0 = self.state.num_samples
+        for t in range(phase, tiles_x * ((h + th - 1) // th), stride):
+            tx, ty = x0 + (t % tiles_x) * tw, y0 + (t // tiles_x) * th
+            self.state.num_samples = n0
+            self.oracle.render(self.state, self.scene, self.scene.camera, self.params, spp,
+                               region=(tx, ty, min(tw, x0 + w - tx), min(th, y0 + h - ty)), sample_offset=self.offset, n_threads=2)
+        self.state.num_samples = n0 + spp
 
     render_async = render
 
@@ -68,8 +84,8 @@ def _worker(rank, world, port, mode, out_path):
     else:
         p = bdpt.default_params()
         r = OracleRenderer(bdpt, oracle, scene, p, seeds)
-        dr.render_tile_split(r, H, W, SPP, world, rank)
-        img = dr.gather_tile_split(torch.from_numpy(r.state.accum), H, world, dist)
+        dr.render_tile_split(r, H, W, SPP, world, rank, tile=(16, 8))
+        img = dr.gather_tile_split(torch.from_numpy(r.state.accum), H, world, dist, tile=(16, 8))
     if rank == 0:
         np.save(out_path, img.numpy())
     else:

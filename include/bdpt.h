@@ -108,9 +108,12 @@ enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_
  * LDS:    the workgroup keeps the whole scene in LDS (scenes up to 24 KB of records).
  * TILED:  per-triangle bounding spheres are staged through wave-private LDS tiles and the
  *         triangle itself is read only for rays that come near it (any scene size).
- * AUTO:   TILED when the scene does not fit the LDS variant or when enough of its triangles are small
- *         against the scene for the bounding spheres to pay (estimated at upload), else LDS. */
-enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4 };
+ * LDS2:   scene in LDS as for LDS (cull records included, so about 130 triangles at most); every
+ *         triangle first gets a cheap conservative test from all lanes together, and each lane
+ *         then runs the reference's test only on the one or two triangles it could not rule out.
+ * AUTO:   TILED when the scene does not fit LDS2 or when enough of its triangles are small
+ *         against the scene for the bounding spheres to pay (estimated at upload), else LDS2. */
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5 };
 
 typedef struct bdpt_params {
     int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */

@@ -50,7 +50,9 @@ struct bdpt_ctx {
     int n_planes = 0, n_triangles = 0;
 
     /* device memory */
-    float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri_bound = nullptr, *d_surf = nullptr;
+    float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri_bound = nullptr, *d_tri_cull = nullptr, *d_surf = nullptr;
+    float *d_tri_cull_s = nullptr;
+    float cull_c = 0.0f;
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -174,7 +176,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_surf);
+    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_tri_cull); dev_free(ctx->d_tri_cull_s); dev_free(ctx->d_surf);
     dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
@@ -232,7 +234,7 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown connection_falloff");
     if (p->accum_mode != BDPT_ACCUM_MEAN && p->accum_mode != BDPT_ACCUM_SUM)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
-    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_TILED)
+    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_LDS2)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
     if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ADAPTIVE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
@@ -289,8 +291,11 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     /* the triangle array carries one zeroed record past the end: the search prefetches record i+1 */
     std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4),
         tri(((size_t)n_triangles + 1) * BDPT_TRI_F4, make_float4(0.f, 0.f, 0.f, 0.f)),
-        bound((size_t)n_triangles + 1, make_float4(0.f, 0.f, 0.f, 0.f)), surf((size_t)n_surfaces * 2);
+        bound((size_t)n_triangles + 1, make_float4(0.f, 0.f, 0.f, 0.f)), cull((size_t)n_triangles * BDPT_CULL_F4),
+        surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
+    std::vector<float> cull_s(n_triangles);
+    double cull_c = 0.0;
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];
         sph[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);   /* kernel0.cl:337 */
@@ -337,6 +342,41 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         const bool well_shaped = std::sqrt(crx * crx + cry * cry + crz * crz) >= 1.0e-3 * longest2;
         bound[i] = make_float4(cx, cy, cz, well_shaped ? std::nextafter((float)(r2 * 1.05), INFINITY) : INFINITY);
         tri_s[i] = t.surface;
+        /* Records of the two-stage kernel's conservative test (closest_hit_lds2, where the margin is derived).
+         * In exact arithmetic the reference's edge expressions (kernel0.cl:298-300) are, for a point p of the
+         * triangle's plane,  dA = (p-a).((c-a) x n),  dB = (p-c).((b-c) x n),  dC = (p-b).((a-b) x n),  each equal
+         * to |(b-a) x (c-a)| at the opposite vertex: divided by that they are barycentric coordinates g_j . p + h_j
+         * that add up to 1.  They are stored times s = h / (104 * 2^-24), h the smallest height. */
+        {
+            const double A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z}, C[3] = {c.x, c.y, c.z};
+            const double area2 = std::sqrt(crx * crx + cry * cry + crz * crz);
+            const double nt[3] = {crx / area2, cry / area2, crz / area2};
+            const double theta = std::sqrt((n.x - nt[0]) * (n.x - nt[0]) + (n.y - nt[1]) * (n.y - nt[1]) + (n.z - nt[2]) * (n.z - nt[2]));
+            const double longest = std::sqrt(longest2);
+            const double scale = (area2 / longest) / (104.0 * 0x1p-24);                    /* s */
+            auto edge_plane = [&](const double *from, const double *to, const double *vertex, float4 &out) {
+                const double e[3] = {to[0] - from[0], to[1] - from[1], to[2] - from[2]};     /* the reference's second cross operand */
+                const double f = scale / area2;
+                const double g[3] = {(e[1] * nt[2] - e[2] * nt[1]) * f, (e[2] * nt[0] - e[0] * nt[2]) * f, (e[0] * nt[1] - e[1] * nt[0]) * f};
+                out = make_float4((float)g[0], (float)g[1], (float)g[2], (float)-(vertex[0] * g[0] + vertex[1] * g[1] + vertex[2] * g[2]));
+            };
+            float4 *q3 = &cull[(size_t)i * BDPT_CULL_F4];
+            q3[0] = make_float4(n.x, n.y, n.z, (float)(A[0] * n.x + A[1] * n.y + A[2] * n.z));
+            edge_plane(A, C, A, q3[1]);                                   /* dA: (p-a) x (c-a) */
+            edge_plane(C, B, C, q3[2]);                                   /* dB: (p-c) x (b-c); dC is what is left of s */
+            double a1 = 0.0;
+            for (const double *v : {A, B, C}) a1 = std::max(a1, std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]));
+            const double c_i = longest + a1 + theta * longest / 3.5e-6;
+            const bool usable = well_shaped && theta < 1.0e-4 && std::isfinite(scale) && scale < 1.0e30 && std::isfinite(c_i) &&
+                                std::isfinite(q3[1].x + q3[1].y + q3[1].z + q3[1].w + q3[2].x + q3[2].y + q3[2].z + q3[2].w);
+            if (usable) {
+                cull_s[i] = (float)scale;
+                cull_c = std::max(cull_c, c_i);
+            } else {                                                      /* every coordinate 0: never below the (negative) bound */
+                cull_s[i] = 0.0f;
+                q3[1] = q3[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
     for (int i = 0; i < n_surfaces; i++) {
         const bdpt_surface &s = surfaces[i];
@@ -352,6 +392,9 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
     HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, bound));
+    HIP_TRY(ctx, dev_upload(ctx->d_tri_cull, cull));
+    HIP_TRY(ctx, dev_upload(ctx->d_tri_cull_s, cull_s));
+    ctx->cull_c = (float)(cull_c * 1.000001);
     HIP_TRY(ctx, dev_upload(ctx->d_surf, surf));
     HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
     HIP_TRY(ctx, dev_upload(ctx->d_pln_surf, pln_s));
@@ -519,7 +562,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     std::memset(&K, 0, sizeof K);
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
-    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.tri_cull_s = ctx->d_tri_cull_s; K.scene.cull_c = ctx->cull_c; K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;
@@ -589,16 +632,18 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     const bool aov = ctx->params.aov_enable != 0;
     if (aov && (rc = ensure_aovs(ctx)) != BDPT_OK) return rc;
     int variant = ctx->params.kernel_variant;
-    if (variant == BDPT_KERNEL_LDS && bdpt_lds_scene_bytes(K.scene) > BDPT_LDS_SCENE_MAX)
+    if ((variant == BDPT_KERNEL_LDS || variant == BDPT_KERNEL_LDS2) &&
+        bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) > BDPT_LDS_SCENE_MAX)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
     /* AUTO: see the estimate in bdpt_upload_scene */
     if (variant == BDPT_KERNEL_AUTO)
-        variant = (bdpt_lds_scene_bytes(K.scene) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS : BDPT_KERNEL_TILED;
+        variant = (bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_TILED;
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
+    else if (variant == BDPT_KERNEL_LDS2) HIP_TRY(ctx, bdpt_launch_lds2(K, aov, ctx->counters_on, ctx->stream));
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;

@@ -282,6 +282,45 @@ BDPT_DEV void test_triangle_scattered(Best &b, float4 q0, float4 q1, float4 q2, 
     if (i != skip) best_consider(b, p, o, 2, i);                                     /* :436, :441-448 */
 }
 
+/*
+ * test_triangle_scattered without branches, for the per-lane second stage of the two-stage kernel, where
+ * nearly every lane that runs the test has a hit: all culls become one predicate and the running best is
+ * updated by selects.  `wanted` = this lane has a triangle to test at all.
+ */
+BDPT_DEV void test_triangle_flat(Best &b, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, float e2z, int i,
+                                 bool wanted, clm_f3 o, clm_f3 d)
+{
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float val = clm_dot3(d, n);                                                      /* :286 */
+    clm_f3 a = clm_make3(q0.w, q1.x, q1.y);
+    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
+    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
+    clm_f3 e0 = clm_make3(q1.z, q1.w, q2.x);
+    clm_f3 c = clm_make3(q2.y, q2.z, q2.w);
+    clm_f3 e1 = clm_make3(q3.x, q3.y, q3.z);
+    clm_f3 bb = clm_make3(q3.w, q4.x, q4.y);
+    clm_f3 e2 = clm_make3(q4.z, q4.w, e2z);
+    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), e0), n);                          /* :298 */
+    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
+    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
+    const bool hit = wanted && !(val > 0) && !(t < 0) && !(dA < 0) && !(dB < 0) && !(dC < 0);   /* :288, :292, :304 */
+    const clm_f3 v = clm_sub3(p, o);
+    const float d2 = clm_dot3(v, v);
+    bool take = hit && d2 < b.d2_lo;
+    const bool close_call = hit && !take && d2 < b.d2;
+    if (__builtin_amdgcn_ballot_w64(close_call) != 0) {
+        asm volatile("");
+        if (close_call) take = clm_sqrt(d2) < clm_sqrt(b.d2);
+    }
+    b.d2 = take ? d2 : b.d2;
+    b.d2_lo = take ? (d2 > 1.0e-30f ? d2 * 0.999999f : 0.0f) : b.d2_lo;
+    b.type = take ? 2 : b.type;
+    b.idx = take ? i : b.idx;
+    b.pos.x = take ? p.x : b.pos.x;
+    b.pos.y = take ? p.y : b.pos.y;
+    b.pos.z = take ? p.z : b.pos.z;
+}
+
 /* kernel0.cl:452-473: surface id, shading normal of the winner, flip toward the ray */
 BDPT_DEV Hit finish_hit(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
 {

@@ -15,8 +15,12 @@ hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream
 
 /* The same work with the whole scene resident in LDS (scenes up to BDPT_LDS_SCENE_MAX bytes of records). */
 #define BDPT_LDS_SCENE_MAX (24u * 1024u)
-size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S);
+size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records);
 hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
+/* LDS-resident scene, triangles in two stages: a conservative test for all lanes together, then the full test
+ * per lane on what is left (the scene's cull records go to LDS as well). */
+hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
 /* The same work for scenes of any size: triangle records staged through wave-private LDS tiles. */
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);

@@ -89,27 +89,34 @@ BDPT_DEV Hit closest_hit_direct(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int
  * 2.0 (tools/valu_issue.hip).                                                  */
 /* ------------------------------------------------------------------------- */
 
-extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | n_spheres | n_planes*2 | n_surfaces*2 | surface ids] */
+extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | (two-stage kernel: n_triangles*5) | n_spheres | n_planes*2 | n_surfaces*2 | surface ids] */
 
 /* offsets, in float4, of the parts that follow the triangle records */
 struct LdsLayout {
-    int sph, pln, surf, ids;        /* spheres, planes, surface table, surface ids (uint32: triangles, spheres, planes) */
+    int cull, sph, pln, surf, ids;  /* cull records, spheres, planes, surface table, surface ids (uint32: triangles, spheres, planes) */
+    int n_ids;                      /* number of surface ids; the two-stage kernel's per-triangle scale factors follow them */
 };
+template <bool CULL>
 BDPT_DEV LdsLayout lds_layout(const bdpt_dev_scene &S)
 {
     LdsLayout L;
-    L.sph = S.n_triangles * BDPT_TRI_F4;
+    L.cull = S.n_triangles * BDPT_TRI_F4;
+    L.sph = L.cull + (CULL ? S.n_triangles * BDPT_CULL_F4 : 0);
     L.pln = L.sph + S.n_spheres;
     L.surf = L.pln + S.n_planes * BDPT_PLN_F4;
     L.ids = L.surf + S.n_surfaces * 2;
+    L.n_ids = S.n_triangles + S.n_spheres + S.n_planes;
     return L;
 }
 
+template <bool CULL>
 BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
 {
-    const LdsLayout L = lds_layout(S);
+    const LdsLayout L = lds_layout<CULL>(S);
     const int n_tri = S.n_triangles * BDPT_TRI_F4, n_pln = S.n_planes * BDPT_PLN_F4, n_surf = S.n_surfaces * 2;
     for (int i = threadIdx.x; i < n_tri; i += blockDim.x) bdpt_lds[i] = S.tri[i];
+    if (CULL)
+        for (int i = threadIdx.x; i < S.n_triangles * BDPT_CULL_F4; i += blockDim.x) bdpt_lds[L.cull + i] = S.tri_cull[i];
     for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) bdpt_lds[L.sph + i] = S.sph[i];
     for (int i = threadIdx.x; i < n_pln; i += blockDim.x) bdpt_lds[L.pln + i] = S.pln[i];
     for (int i = threadIdx.x; i < n_surf; i += blockDim.x) bdpt_lds[L.surf + i] = S.surf[i];
@@ -117,13 +124,18 @@ BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
     for (int i = threadIdx.x; i < S.n_triangles; i += blockDim.x) ids[i] = S.tri_surf[i];
     for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) ids[S.n_triangles + i] = S.sph_surf[i];
     for (int i = threadIdx.x; i < S.n_planes; i += blockDim.x) ids[S.n_triangles + S.n_spheres + i] = S.pln_surf[i];
+    if (CULL) {
+        float *cs = (float *)(ids + L.n_ids);
+        for (int i = threadIdx.x; i < S.n_triangles; i += blockDim.x) cs[i] = S.tri_cull_s[i];
+    }
     __syncthreads();
 }
 
 /* finish_hit (bdpt_device.h) reading the winner's record and surface id from LDS */
+template <bool CULL>
 BDPT_DEV Hit finish_hit_lds(const bdpt_dev_scene &S, const Best &b, clm_f3 d)
 {
-    const LdsLayout L = lds_layout(S);
+    const LdsLayout L = lds_layout<CULL>(S);
     const uint32_t *ids = (const uint32_t *)(bdpt_lds + L.ids);
     Hit h;
     h.type = b.type;
@@ -156,7 +168,7 @@ BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int ot
     const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
     const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
     const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
-    const LdsLayout L = lds_layout(S);
+    const LdsLayout L = lds_layout<false>(S);
     const int sph0 = L.sph, pln0 = L.pln;
     for (int i = 0; i < S.n_spheres; i++) {
         const float4 s = bdpt_lds[sph0 + i];
@@ -176,22 +188,136 @@ BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int ot
         if (SCATTERED) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
         else if (i != skip_t) test_triangle(b, q0, q1, q2, q3, q4, e2z, i, o, d);
     }
-    return finish_hit_lds(S, b, d);
+    return finish_hit_lds<false>(S, b, d);
 }
 
-enum { MODE_DIRECT = 0, MODE_DUAL = 1, MODE_LDS = 2 };
+/* ------------------------------------------------------------------------- */
+/* Two-stage LDS-resident variant.  In the walk above a wavefront runs the whole
+ * triangle test for a triangle as soon as one of its 64 rays passes the plane
+ * culls, with the other lanes idle: for rays that point every way that is nearly
+ * every triangle, although each ray hits one or two of them.  Here the walk is
+ * split in two:
+ *
+ *  stage 1, all lanes together, no branches: a conservative test of every triangle.
+ *    val = d.n is the reference's own value (kernel0.cl:286), so its cull (:288)
+ *    is decided exactly.  The point p' where the ray meets the triangle's plane is
+ *    then formed with approximate arithmetic (a precomputed a.n, v_rcp_f32) and
+ *    its barycentric coordinates are read off precomputed edge planes (3 fma each
+ *    instead of the 12 operations of a cross and a dot product; the third is what
+ *    is left of the sum).  The triangle is dropped for this ray only if the
+ *    smallest coordinate is negative by more than rounding can explain.
+ *
+ *    The margin.  Let u = 2^-24.  The reference's numerator (a-o).n and this
+ *    stage's k - o.n each carry at most 4u (|a|_1 + |o|_1); divided by val that
+ *    moves the point along the ray by 8u (|a|_1 + |o|_1) |d| / |val|; the quotient,
+ *    the fma that forms the point, and the difference p - a add some u (|a| + L +
+ *    |o|) (L = longest edge; a point the reference accepts lies within the
+ *    triangle up to such terms).  A coordinate changes by at most 1/h per unit of
+ *    point movement (h = the triangle's smallest height); the reference's own
+ *    cross and dot product are good to 42 u L |e| against the doubled area, i.e.
+ *    42 u L / h; the stored planes and their fma chain to 4 u sqrt(3) (2|a| + L) / h;
+ *    the angle theta between the reference's float normal and the true one tilts
+ *    the reference's expressions by theta L / h.  With |d|_inf / |val| >= 1/sqrt(3)
+ *    all of it is below
+ *        (104 u / h) (L + |a|_1 + |o|_1 + theta L / 3.5e-6) |d|_inf / |val| .
+ *    Upload scales each triangle's coordinates by s = h / (104 u), takes C = the
+ *    largest L + |a|_1 + theta L / 3.5e-6 of the scene, and the device compares the
+ *    smallest scaled coordinate with -(C + |o|_1) |d|_inf / |val|, doubled for
+ *    good measure.  A NaN or an infinity anywhere fails the comparison and keeps
+ *    the triangle; triangles whose normal is unreliable have s = 0 and all-zero
+ *    planes, which keeps them for every ray.  Each lane ends with a bit mask of
+ *    the triangles it could not rule out.
+ *
+ *  stage 2, per lane: the reference's test (test_triangle_flat, the arithmetic of
+ *    test_triangle_scattered) on the lane's remaining triangles, in ascending index
+ *    order, each lane reading its own triangle's record from LDS.  A ray keeps one
+ *    triangle, seldom two, so the wavefront makes one or two passes here instead
+ *    of one per triangle.
+ *
+ * Every triangle the reference's test would accept survives stage 1, candidates
+ * go through the reference's arithmetic in the reference's order, so results are
+ * bit-identical with the other variants.                                       */
+/* ------------------------------------------------------------------------- */
+
+template <bool COUNT>
+BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx,
+                              unsigned long long *n_cull, unsigned long long *n_exact)
+{
+    Best b;
+    best_init(b);                                                         /* kernel0.cl:374, :384-385 */
+    const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
+    const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
+    const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
+    const LdsLayout L = lds_layout<true>(S);
+    for (int i = 0; i < S.n_spheres; i++) {
+        const float4 s = bdpt_lds[L.sph + i];
+        if (i != skip_s) test_sphere(b, s, i, o, d);
+    }
+    for (int i = 0; i < S.n_planes; i++) {
+        const float4 q0 = bdpt_lds[L.pln + i * BDPT_PLN_F4], q1 = bdpt_lds[L.pln + i * BDPT_PLN_F4 + 1];
+        if (i != skip_p) test_plane(b, q0, q1, i, o, d);
+    }
+    /* (C + |o|_1) |d|_inf, doubled: the ray's part of the margin */
+    const float ray_margin = 2.0f * (S.cull_c + fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) * fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float *cull_s = (const float *)(bdpt_lds + L.ids) + L.n_ids;
+    for (int base = 0; base < S.n_triangles; base += 32) {
+        const int cnt = min(32, S.n_triangles - base);
+        uint32_t mask = 0u;
+        for (int j = 0; j < cnt; j++) {                                   /* stage 1 */
+            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+            const float sc = cull_s[base + j];
+            const float val = clm_dot3(d, clm_make3(c0.x, c0.y, c0.z));                               /* :286, exact */
+            const float num = __builtin_fmaf(-o.z, c0.z, __builtin_fmaf(-o.y, c0.y, __builtin_fmaf(-o.x, c0.x, c0.w)));
+            const float r = __builtin_amdgcn_rcpf(val);
+            const float t = num * r;
+            const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
+            const float b0 = __builtin_fmaf(pz, c1.z, __builtin_fmaf(py, c1.y, __builtin_fmaf(px, c1.x, c1.w)));
+            const float b1 = __builtin_fmaf(pz, c2.z, __builtin_fmaf(py, c2.y, __builtin_fmaf(px, c2.x, c2.w)));
+            const float b2 = (sc - b0) - b1;
+            const float m = __builtin_fminf(__builtin_fminf(b0, b1), b2);
+            /* val <= 0 for a triangle that is kept, so |1/val| = -r; a front-facing ray (val > 0, :288) makes -val negative */
+            const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, r, m), -val);
+            mask |= (z < 0.0f) ? 0u : (1u << j);
+        }
+        if (COUNT) *n_cull += (unsigned long long)cnt;
+        if (skip_t >= base && skip_t < base + 32) mask &= ~(1u << (skip_t - base));                   /* :436 */
+        while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0) {            /* stage 2 */
+            const bool wanted = mask != 0u;
+            const int i = base + (wanted ? __builtin_ctz(mask) : 0);      /* a lane with nothing left reads a record it ignores */
+            mask &= mask - 1u;
+            const int r = i * BDPT_TRI_F4;
+            const float4 q0 = bdpt_lds[r], q1 = bdpt_lds[r + 1], q2 = bdpt_lds[r + 2], q3 = bdpt_lds[r + 3],
+                         q4 = bdpt_lds[r + 4];
+            const float e2z = bdpt_lds[r + 5].x;
+            test_triangle_flat(b, q0, q1, q2, q3, q4, e2z, i, wanted, o, d);
+            if (COUNT && wanted) ++*n_exact;
+        }
+    }
+    return finish_hit_lds<true>(S, b, d);
+}
+
+enum { MODE_DIRECT = 0, MODE_DUAL = 1, MODE_LDS = 2, MODE_LDS2 = 3 };
+
+/* per-lane work counters of a counting launch */
+struct Tally {
+    unsigned long long rays, full, early, cull, exact;
+};
 
 /* row `i` of the surface table (2 float4 per surface: colour, emissive) */
 template <int MODE>
 BDPT_DEV float4 surface_row(const bdpt_dev_scene &S, uint32_t i)
 {
-    return MODE == MODE_LDS ? bdpt_lds[lds_layout(S).surf + (int)i] : S.surf[i];
+    if (MODE == MODE_LDS) return bdpt_lds[lds_layout<false>(S).surf + (int)i];
+    if (MODE == MODE_LDS2) return bdpt_lds[lds_layout<true>(S).surf + (int)i];
+    return S.surf[i];
 }
 
 /* SCATTERED: the rays of a wavefront point in unrelated directions (every ray but the eye ray) */
-template <int MODE, bool SCATTERED>
-BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx)
+template <int MODE, bool SCATTERED, bool COUNT>
+BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx, Tally &T)
 {
+    if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact);
     return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
 }
 
@@ -201,15 +327,15 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
 /* ALT: bounce directions from one of the samplers the reference holds but does not call (K.sampler).
  * ALL_RAYS: also trace the rays whose result nothing but the ray counters and the hit-id chain can
  * see (the bounce ray of the last vertex, kernel0.cl:793 at lti = maxL-1). */
-template <bool AOV, int MODE, bool ALT, bool ALL_RAYS>
+template <bool AOV, int MODE, bool ALT, bool ALL_RAYS, bool COUNT>
 BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
-                            uint32_t &hash, int eye_id[2], float col[4])
+                            uint32_t &hash, int eye_id[2], float col[4], Tally &T)
 {
     const bdpt_dev_scene &S = K.scene;
     rng_float(w, draws);                                                  /* :592, discarded */
     clm_f3 dir = camera_ray(w, draws, K, xt, yt);
     clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
-    Hit eye = trace_one<MODE, false>(S, eye_pos, dir, 4, 0);                  /* :634 */
+    Hit eye = trace_one<MODE, false, COUNT>(S, eye_pos, dir, 4, 0, T);        /* :634 */
     rays++;
     if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
 
@@ -236,7 +362,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
         if (ALL_RAYS || !K.indirect_only || lti != 0) {                   /* INDIRECT_ONLY drops the light's own connection (:752-755) */
             clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));        /* :699 */
-            Hit vis = trace_one<MODE, true>(S, vpos, tdir, vtype, vidx);  /* :705 */
+            Hit vis = trace_one<MODE, true, COUNT>(S, vpos, tdir, vtype, vidx, T);  /* :705 */
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
             float contrib[4];
@@ -263,7 +389,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         clm_f3 ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming)
                           : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
 
-        Hit nxt = trace_one<MODE, true>(S, lpos, ldir, vtype, vidx);         /* :793 */
+        Hit nxt = trace_one<MODE, true, COUNT>(S, lpos, ldir, vtype, vidx, T);   /* :793 */
         rays++;
         if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
         if (nxt.type < 0) break;                                          /* :812 */
@@ -294,10 +420,14 @@ BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, 
  * register allocator would settle for at 94 VGPRs; seven and eight spill too much.  The two-ray
  * variant needs its registers. */
 template <bool AOV, bool COUNT, int MODE, bool ALT>
-__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : 6, MODE == MODE_DUAL ? 4 : 6)))
+#ifndef BDPT_LDS2_WAVES
+#define BDPT_LDS2_WAVES 6
+#endif
+__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_DUAL ? 4 : MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
-    if (MODE == MODE_LDS) lds_fill_scene(K.scene);   /* every thread of the workgroup, before any early exit */
+    if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
+    if (MODE == MODE_LDS2) lds_fill_scene<true>(K.scene);
     int x, y;
     lane_pixel(K, x, y);
     if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
@@ -312,7 +442,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
-    unsigned long long c_rays = 0, c_full = 0, c_early = 0;
+    Tally T = {0, 0, 0, 0, 0};
     int eye_id[2] = {-1, -1};
     float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -324,10 +454,10 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         uint32_t wp = cur.st_head, dp = 0;
         rng_float(wp, dp);                                                /* :592 */
         const clm_f3 dir = camera_ray(wp, dp, K, xt, yt);
-        const Hit e = trace_one<MODE == MODE_DUAL ? MODE_DIRECT : MODE, false>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0);
+        const Hit e = trace_one<MODE == MODE_DUAL ? MODE_DIRECT : MODE, false, COUNT>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0, T);
         const bool early = e.type < 0 || surface_row<MODE>(K.scene, e.surf * 2 + 1).w != 0.0f;   /* :645-656 */
         if (early) cur.cls = -1;
-        if (COUNT && !AOV) c_rays++;                 /* a ray this launch form traces on top of the samples' own */
+        if (COUNT && !AOV) T.rays++;                 /* a ray this launch form traces on top of the samples' own */
     }
 
     uint32_t start;
@@ -337,8 +467,8 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                             : sample_direct<AOV, MODE, ALT, AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col);
-        if (COUNT) { c_rays += rays - rays_before; if (early) c_early++; else c_full++; }
+                                             : sample_direct<AOV, MODE, ALT, AOV, COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col, T);
+        if (COUNT) { T.rays += rays - rays_before; if (early) T.early++; else T.full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
             /* kernel0.cl:645-656: raw value written, history dropped, the seed is not
@@ -353,7 +483,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
                 draws += 3u * (uint32_t)rest;
                 rays += (uint32_t)rest;
             }
-            if (COUNT) c_early += (unsigned long long)rest;
+            if (COUNT) T.early += (unsigned long long)rest;
             break;
         }
         if (n == 0) {                                                     /* :855 */
@@ -381,9 +511,11 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         K.aov_rays[pix] = rays;
     }
     if (COUNT) {
-        atomicAdd(&K.counters[0], c_rays);
-        atomicAdd(&K.counters[1], c_full);
-        atomicAdd(&K.counters[2], c_early);
+        atomicAdd(&K.counters[0], T.rays);
+        atomicAdd(&K.counters[1], T.full);
+        atomicAdd(&K.counters[2], T.early);
+        atomicAdd(&K.counters[3], T.cull);
+        atomicAdd(&K.counters[4], T.exact);
     }
 }
 
@@ -854,8 +986,8 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
     const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
     if (grid.x == 0) return hipSuccess;                  /* this share owns no tile of the region */
     size_t lds = 0;
-    if (MODE == bdpt::MODE_LDS) {
-        lds = bdpt_lds_scene_bytes(K.scene);
+    if (MODE == bdpt::MODE_LDS || MODE == bdpt::MODE_LDS2) {
+        lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2);
         if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
     }
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
@@ -877,11 +1009,11 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
     return hipGetLastError();
 }
 
-size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S)
+size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records)
 {
-    const size_t ids = ((size_t)S.n_triangles + S.n_spheres + S.n_planes + 3) / 4;   /* uint32 ids, in float4 */
-    return ((size_t)S.n_triangles * BDPT_TRI_F4 + (size_t)S.n_spheres + (size_t)S.n_planes * BDPT_PLN_F4 +
-            (size_t)S.n_surfaces * 2 + ids) * sizeof(float4);
+    const size_t ids = ((size_t)S.n_triangles * (with_cull_records ? 2 : 1) + S.n_spheres + S.n_planes + 3) / 4;   /* uint32 ids (+ float scale factors), in float4 */
+    return ((size_t)S.n_triangles * (BDPT_TRI_F4 + (with_cull_records ? BDPT_CULL_F4 : 0)) + (size_t)S.n_spheres +
+            (size_t)S.n_planes * BDPT_PLN_F4 + (size_t)S.n_surfaces * 2 + ids) * sizeof(float4);
 }
 
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
@@ -897,6 +1029,11 @@ hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream
 hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     return launch_per_pixel<bdpt::MODE_LDS>(K, aov, count, stream);
+}
+
+hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    return launch_per_pixel<bdpt::MODE_LDS2>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)

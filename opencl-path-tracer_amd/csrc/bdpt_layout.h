@@ -21,6 +21,15 @@
  *   triangle bound 1 x float4 : (centre.xyz, 1.05 * radius^2) of a sphere around the three
  *       vertices: what the tiled kernel streams; a ray that passes the sphere by more than
  *       rounding can explain cannot hit the triangle, and only the others read the record
+ *   triangle cull 3 x float4 + 1 float : what the two-stage LDS kernel's conservative test reads, computed
+ *       in double at upload and rounded (the test carries a margin for that, see closest_hit_lds2):
+ *       c0 (n.x, n.y, n.z, k)       n as in q0 (the reference's normal, same bits), k = a.n
+ *       c1 (g0.x, g0.y, g0.z, h0)   g_j . p + h_j = the reference's j-th edge expression (kernel0.cl:298-300)
+ *       c2 (g1.x, g1.y, g1.z, h1)   for a point p of the triangle's plane, as a barycentric coordinate (1 at the
+ *                                   opposite vertex) times s; the third coordinate is s minus the other two
+ *       s                           1 / (error of a coordinate per unit of the ray-dependent factor): in these
+ *                                   units every triangle has the same margin; 0 (with g = h = 0) switches the
+ *                                   test off for a triangle it cannot be trusted on (slivers)
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
  * winning primitive only).
@@ -33,6 +42,7 @@
 
 #define BDPT_TRI_F4 6
 #define BDPT_PLN_F4 2
+#define BDPT_CULL_F4 3      /* + one float per triangle in a separate array (tri_cull_s) */
 
 struct bdpt_dev_scene {
     const float4 *sph;          /* [n_spheres] */
@@ -41,6 +51,9 @@ struct bdpt_dev_scene {
     const uint32_t *pln_surf;   /* [n_planes] */
     const float4 *tri;          /* [(n_triangles + 1) * BDPT_TRI_F4] */
     const float4 *tri_bound;    /* [n_triangles + 1] bounding spheres */
+    const float4 *tri_cull;     /* [n_triangles * BDPT_CULL_F4] records of the conservative test */
+    const float *tri_cull_s;    /* [n_triangles] */
+    float cull_c;               /* scene constant of that test's margin */
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;

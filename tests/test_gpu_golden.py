@@ -7,12 +7,14 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", gu.RENDER_CASES)
 def test_render_matches_golden(bdpt, case, variant):
     g = gu.load(case)
     scene, p, W, H, spp, off = gu.unpack(bdpt, g)
     p.kernel_variant = variant
+    if variant in (bdpt.KERNEL_LDS, bdpt.KERNEL_LDS2) and len(scene.triangles) * (96 + (80 if variant == bdpt.KERNEL_LDS2 else 0)) > 20000:
+        pytest.skip("scene too large for the LDS-resident kernels")
     with bdpt.Context(W, H) as ctx:
         ctx.set_params(p)
         ctx.upload_scene(scene)
@@ -45,7 +47,7 @@ def test_closest_hit_matches_golden(bdpt):
 
 def _region_variants(case):
     # the 100 000-triangle scene does not fit the LDS-resident kernel; AUTO must resolve to TILED there
-    return [0, 1, 4] if "soup100k" in case else [0, 1, 2, 3, 4]
+    return [0, 1, 4] if "soup100k" in case else [0, 1, 2, 3, 4, 5]
 
 
 @pytest.mark.parametrize("case,variant", [(c, v) for c in gu.REGION_CASES for v in _region_variants(c)])

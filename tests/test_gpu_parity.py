@@ -138,7 +138,7 @@ def test_near_ties_resolve_like_the_reference_order(bdpt, oracle):
     ctx.close()
 
 
-VARIANTS = [1, 2, 3, 4]   # DIRECT, DUAL, LDS, TILED: every kernel variant must give the same bits
+VARIANTS = [1, 2, 3, 4, 5]   # DIRECT, DUAL, LDS, TILED, LDS2: every kernel variant must give the same bits
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -295,7 +295,7 @@ def test_sample_orders_take_the_same_samples(bdpt, oracle, variant, p_continue, 
     np.testing.assert_allclose(a[0], b[0], rtol=2e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("sampler", [1, 2])
 def test_alternative_samplers_match_the_oracle(bdpt, oracle, variant, sampler):
     """HEMISPHERE and REFLECTIVE bounce samplers: per-sample parity in STREAM mode and a class-ordered STRIDED + SUM
@@ -368,8 +368,23 @@ def test_tiled_kernel_bounding_sphere_cull_never_drops_a_hit(bdpt, oracle, seed,
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_two_stage_kernel_conservative_test_never_drops_a_hit(bdpt, oracle, seed):
+    """The two-stage LDS kernel rules a triangle out for a ray with an approximate test and a margin.  Specks,
+    slivers down to where the normal is noise, wall-sized sheets, triangles far outside, seen by eye, connection
+    and bounce rays (grazing ones included): every id, count and bit as the oracle."""
+    scene = _mixed_soup(bdpt, 110, seed)
+    W, H = 64, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_LDS2)
+    for s in range(3):
+        ctx.render(3)
+        oracle.render(st, scene, scene.camera, p, 3, n_threads=8)
+        _compare(bdpt, ctx, st, "two-stage, mixed soup %d launch %d:" % (seed, s))
+    ctx.close()
+
+
 def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
-    """AUTO: the Cornell box (12 wall-sized triangles) stays in LDS, also with a 12-triangle box added; a few dozen
+    """AUTO: the Cornell box (12 wall-sized triangles) stays in LDS (two-stage kernel), also with a few more triangles; a few dozen
     small triangles tip it to the tiled kernel with its bounding-sphere test; a scene too large for LDS always."""
     def variant_for(scene):
         with bdpt.Context(32, 32) as ctx:
@@ -379,9 +394,9 @@ def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
             assert ctx.last_launch_variant() == 0
             ctx.render(1)
             return ctx.last_launch_variant()
-    assert variant_for(bdpt.Scene.cornell()) == bdpt.KERNEL_LDS
-    assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS
-    assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS
+    assert variant_for(bdpt.Scene.cornell()) == bdpt.KERNEL_LDS2
+    assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS2
+    assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS2
     assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_TILED
     assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_TILED
 
@@ -396,7 +411,7 @@ def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
         spp = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 65, 97, 150]))
         kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, max_light_bounces=int(rng.integers(1, 10)),
                   p_continue=float(rng.uniform(0.05, 0.97)), sampler=int(rng.choice([0, 0, 1, 2])),
-                  kernel_variant=int(rng.choice([0, 1, 3, 4])))
+                  kernel_variant=int(rng.choice([0, 1, 3, 4, 5])))
         # STRIDED keeps the samples of a pixel 32 draws apart: at most 7 vertices (5 with the REFLECTIVE sampler)
         kw["max_light_bounces"] = min(kw["max_light_bounces"], 5 if kw["sampler"] == 2 else 7)
         offset = int(rng.integers(0, 5000))
@@ -409,7 +424,7 @@ def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("mode", ["stream", "strided_sum", "strided_mean"])
 def test_launches_without_parity_buffers_give_the_same_image_and_seeds(bdpt, oracle, variant, mode):
     """With aov_enable = 0 the kernels leave out work only the parity buffers can see (the bounce ray of the last

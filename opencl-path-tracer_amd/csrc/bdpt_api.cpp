@@ -53,6 +53,7 @@ struct bdpt_ctx {
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri_bound = nullptr, *d_tri_cull = nullptr, *d_surf = nullptr;
     float *d_tri_cull_s = nullptr;
     float cull_c = 0.0f;
+    uint32_t cull_same[BDPT_CULL_MAX_TRIANGLES / 32] = {};
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -296,6 +297,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     std::vector<float> cull_s(n_triangles);
     double cull_c = 0.0;
+    std::memset(ctx->cull_same, 0, sizeof ctx->cull_same);
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];
         sph[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);   /* kernel0.cl:337 */
@@ -369,6 +371,11 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             const double c_i = longest + a1 + theta * longest / 3.5e-6;
             const bool usable = well_shaped && theta < 1.0e-4 && std::isfinite(scale) && scale < 1.0e30 && std::isfinite(c_i) &&
                                 std::isfinite(q3[1].x + q3[1].y + q3[1].z + q3[1].w + q3[2].x + q3[2].y + q3[2].z + q3[2].w);
+            /* same plane as the triangle before (bit-identical normal and a.n): the device reuses that triangle's
+             * plane intersection */
+            if (i > 0 && (i & 31) != 0 && i < BDPT_CULL_MAX_TRIANGLES &&
+                std::memcmp(&q3[0], &cull[(size_t)(i - 1) * BDPT_CULL_F4], sizeof(float4)) == 0)
+                ctx->cull_same[i >> 5] |= 1u << (i & 31);
             if (usable) {
                 cull_s[i] = (float)scale;
                 cull_c = std::max(cull_c, c_i);
@@ -562,7 +569,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     std::memset(&K, 0, sizeof K);
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
-    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.tri_cull_s = ctx->d_tri_cull_s; K.scene.cull_c = ctx->cull_c; K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.tri_cull_s = ctx->d_tri_cull_s; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_same, ctx->cull_same, sizeof K.scene.cull_same); K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;

@@ -105,7 +105,7 @@ BDPT_DEV LdsLayout lds_layout(const bdpt_dev_scene &S)
     L.pln = L.sph + S.n_spheres;
     L.surf = L.pln + S.n_planes * BDPT_PLN_F4;
     L.ids = L.surf + S.n_surfaces * 2;
-    L.n_ids = S.n_triangles + S.n_spheres + S.n_planes;
+    L.n_ids = (S.n_triangles + S.n_spheres + S.n_planes + 3) & ~3;   /* rounded up: what follows stays 16-byte aligned */
     return L;
 }
 
@@ -249,10 +249,17 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
     const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
     const LdsLayout L = lds_layout<true>(S);
+#ifdef BDPT_DBG_TWICE_SPHERES
+    for (int rep = 0; rep < 2; rep++) {
+    asm volatile("" : "+v"(o.x), "+v"(d.x));
+#endif
     for (int i = 0; i < S.n_spheres; i++) {
         const float4 s = bdpt_lds[L.sph + i];
         if (i != skip_s) test_sphere(b, s, i, o, d);
     }
+#ifdef BDPT_DBG_TWICE_SPHERES
+    }
+#endif
     for (int i = 0; i < S.n_planes; i++) {
         const float4 q0 = bdpt_lds[L.pln + i * BDPT_PLN_F4], q1 = bdpt_lds[L.pln + i * BDPT_PLN_F4 + 1];
         if (i != skip_p) test_plane(b, q0, q1, i, o, d);
@@ -263,25 +270,68 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     for (int base = 0; base < S.n_triangles; base += 32) {
         const int cnt = min(32, S.n_triangles - base);
         uint32_t mask = 0u;
-        for (int j = 0; j < cnt; j++) {                                   /* stage 1 */
-            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
-            const float4 c0 = c[0], c1 = c[1], c2 = c[2];
-            const float sc = cull_s[base + j];
-            const float val = clm_dot3(d, clm_make3(c0.x, c0.y, c0.z));                               /* :286, exact */
+#ifdef BDPT_DBG_TWICE_STAGE1      /* timing experiment: the same masks computed twice */
+        for (int rep = 0; rep < 2; rep++) {
+        asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(mask));
+#endif
+        const uint32_t same = S.cull_same[base >> 5];
+        /* the plane part of a triangle's test: val (exact, :286), -1/val... and the approximate point on the plane */
+        struct PlaneHit { float val, r, px, py, pz; };
+        auto plane_part = [&](const float4 c0) {
+            PlaneHit h;
+            h.val = clm_dot3(d, clm_make3(c0.x, c0.y, c0.z));
             const float num = __builtin_fmaf(-o.z, c0.z, __builtin_fmaf(-o.y, c0.y, __builtin_fmaf(-o.x, c0.x, c0.w)));
-            const float r = __builtin_amdgcn_rcpf(val);
-            const float t = num * r;
-            const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
-            const float b0 = __builtin_fmaf(pz, c1.z, __builtin_fmaf(py, c1.y, __builtin_fmaf(px, c1.x, c1.w)));
-            const float b1 = __builtin_fmaf(pz, c2.z, __builtin_fmaf(py, c2.y, __builtin_fmaf(px, c2.x, c2.w)));
+            h.r = __builtin_amdgcn_rcpf(h.val);
+            const float t = num * h.r;
+            h.px = __builtin_fmaf(t, d.x, o.x);
+            h.py = __builtin_fmaf(t, d.y, o.y);
+            h.pz = __builtin_fmaf(t, d.z, o.z);
+            return h;
+        };
+        /* the triangle part: is the point outside by more than the margin?  (val <= 0 for a triangle that is kept, so
+         * |1/val| = -r; a front-facing ray, val > 0 (:288), makes -val negative) */
+        auto kept = [&](const PlaneHit &h, const float4 c1, const float4 c2, const float sc) {
+            const float b0 = __builtin_fmaf(h.pz, c1.z, __builtin_fmaf(h.py, c1.y, __builtin_fmaf(h.px, c1.x, c1.w)));
+            const float b1 = __builtin_fmaf(h.pz, c2.z, __builtin_fmaf(h.py, c2.y, __builtin_fmaf(h.px, c2.x, c2.w)));
             const float b2 = (sc - b0) - b1;
             const float m = __builtin_fminf(__builtin_fminf(b0, b1), b2);
-            /* val <= 0 for a triangle that is kept, so |1/val| = -r; a front-facing ray (val > 0, :288) makes -val negative */
-            const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, r, m), -val);
-            mask |= (z < 0.0f) ? 0u : (1u << j);
+            const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m), -h.val);
+            return !(z < 0.0f);
+        };
+        int j = 0;
+        for (; j + 2 <= cnt; j += 2) {                                    /* stage 1, two triangles per round */
+            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
+            const float2 sc = *(const float2 *)(cull_s + base + j);       /* base and j are even, the array 8-byte aligned */
+            bool k0, k1;
+            if ((same >> (j + 1)) & 1u) {                                 /* wave-uniform: the second lies in the first one's plane */
+                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c4 = c[4], c5 = c[5];
+                const PlaneHit h = plane_part(c0);
+                k0 = kept(h, c1, c2, sc.x);
+                k1 = kept(h, c4, c5, sc.y);
+            } else {
+                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+                const PlaneHit h0 = plane_part(c0), h1 = plane_part(c3);
+                k0 = kept(h0, c1, c2, sc.x);
+                k1 = kept(h1, c4, c5, sc.y);
+            }
+            mask |= (k0 ? (1u << j) : 0u) | (k1 ? (2u << j) : 0u);
         }
+        if (j < cnt) {
+            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
+            const PlaneHit h = plane_part(c[0]);
+            mask |= kept(h, c[1], c[2], cull_s[base + j]) ? (1u << j) : 0u;
+        }
+#ifdef BDPT_DBG_TWICE_STAGE1
+        }
+#endif
         if (COUNT) *n_cull += (unsigned long long)cnt;
         if (skip_t >= base && skip_t < base + 32) mask &= ~(1u << (skip_t - base));                   /* :436 */
+#ifdef BDPT_DBG_TWICE_STAGE2      /* timing experiment: every candidate tested twice (the second time changes nothing) */
+        const uint32_t mask_again = mask;
+        for (int rep = 0; rep < 2; rep++) {
+        asm volatile("" : "+v"(o.x), "+v"(d.x));
+        mask = mask_again;
+#endif
         while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0) {            /* stage 2 */
             const bool wanted = mask != 0u;
             const int i = base + (wanted ? __builtin_ctz(mask) : 0);      /* a lane with nothing left reads a record it ignores */
@@ -293,6 +343,9 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             test_triangle_flat(b, q0, q1, q2, q3, q4, e2z, i, wanted, o, d);
             if (COUNT && wanted) ++*n_exact;
         }
+#ifdef BDPT_DBG_TWICE_STAGE2
+        }
+#endif
     }
     return finish_hit_lds<true>(S, b, d);
 }
@@ -989,6 +1042,7 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
     if (MODE == bdpt::MODE_LDS || MODE == bdpt::MODE_LDS2) {
         lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2);
         if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
+        if (MODE == bdpt::MODE_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return hipErrorInvalidValue;
     }
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
     if (alt && MODE == bdpt::MODE_DUAL) return hipErrorInvalidValue;
@@ -1011,7 +1065,8 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
 
 size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records)
 {
-    const size_t ids = ((size_t)S.n_triangles * (with_cull_records ? 2 : 1) + S.n_spheres + S.n_planes + 3) / 4;   /* uint32 ids (+ float scale factors), in float4 */
+    size_t ids = ((size_t)S.n_triangles + S.n_spheres + S.n_planes + 3) / 4;               /* uint32 ids, in float4 */
+    if (with_cull_records) ids += ((size_t)S.n_triangles + 3) / 4;                          /* float scale factors */
     return ((size_t)S.n_triangles * (BDPT_TRI_F4 + (with_cull_records ? BDPT_CULL_F4 : 0)) + (size_t)S.n_spheres +
             (size_t)S.n_planes * BDPT_PLN_F4 + (size_t)S.n_surfaces * 2 + ids) * sizeof(float4);
 }

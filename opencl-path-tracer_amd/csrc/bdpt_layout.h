@@ -42,6 +42,7 @@
 
 #define BDPT_TRI_F4 6
 #define BDPT_PLN_F4 2
+#define BDPT_CULL_MAX_TRIANGLES 256   /* the two-stage kernel's scenes are bounded by LDS well below this */
 #define BDPT_CULL_F4 3      /* + one float per triangle in a separate array (tri_cull_s) */
 
 struct bdpt_dev_scene {
@@ -54,6 +55,9 @@ struct bdpt_dev_scene {
     const float4 *tri_cull;     /* [n_triangles * BDPT_CULL_F4] records of the conservative test */
     const float *tri_cull_s;    /* [n_triangles] */
     float cull_c;               /* scene constant of that test's margin */
+    /* bit i (word i / 32): triangle i lies in the plane of triangle i - 1 (same normal bits, same k) and is not the
+     * first of its group of 32: the two-stage kernel then reuses the plane part of triangle i - 1's test */
+    uint32_t cull_same[BDPT_CULL_MAX_TRIANGLES / 32];
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;

@@ -99,8 +99,24 @@ enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2,
  * REFLECTIVE:   brdf_reflective, kernel0.cl:492-508: one more draw p4 first; p4 > 0.6f samples a
  *               cone of half-angle 3.1415f*0.02f about the mirror image of the direction the subpath
  *               arrived from (the zero vector at the light, as kernel0.cl:659 initialises it), else
- *               the Lambert cone (four draws).  Not available in the DUAL kernel variant. */
-enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_REFLECTIVE = 2 };
+ *               the Lambert cone (four draws).  Not available in the DUAL kernel variant.
+ * LAMBERT_IMP:  brdf_lambertian_imp, kernel0.cl:512-543: one more draw p4 first; p4 > imp_light_weight samples
+ *               a cone of half-angle 0.50f*M_PI about the normal, else a cone of half-angle imp_half_angle
+ *               about the direction toward the light (the only call the file holds, commented out at :945,
+ *               aims at a fixed point; here it is the centre of the light sphere); four draws.  The density
+ *               the function also returns (:527-540) is not used by the live kernel (:772-778). */
+enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_REFLECTIVE = 2, BDPT_SAMPLER_LAMBERT_IMP = 3 };
+/* Which of the two kernels of the reference's file a render call evaluates.
+ * BIDIRECTIONAL: bi_directional_path_trace, kernel0.cl:571-864, the live kernel (everything else in this header).
+ * PATH_TRACE:    path_trace, kernel0.cl:872-1001, the older unidirectional kernel the file keeps commented out:
+ *                up to four rays per sample from the eye, brdf_reflective at every vertex (:943), a surface's
+ *                colour or a light's emission times 1/(2 pi) / weight per hit, sky colour (0.3, 0.3, 0.4, 0.3)
+ *                on a miss (:979) and (0.3, 0.3, 0.3, 0.3) when the fifth vertex is reached (:957).  A render
+ *                call of spp samples is one launch of that kernel with sampleRate = spp: one discarded draw
+ *                (:892), then spp samples blended into the running mean (:990-995).  Needs rng_mode STREAM and
+ *                accum_mode MEAN; sampler, light and roulette parameters do not apply.  One plain kernel,
+ *                whatever kernel_variant says; offered for completeness, not tuned. */
+enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
 /* Kernel variants; all give identical results.
  * DIRECT: every lane walks the primitive arrays with wave-uniform scalar loads.
  * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
@@ -127,7 +143,7 @@ typedef struct bdpt_params {
      * any rank can render any sample range; early-outs are ordinary samples.
      * A sample draws 5 + 4 per light-subpath vertex numbers, the first of them
      * discarded (kernel0.cl:592): no number is used by two samples while
-     * max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler's extra draw per vertex);
+     * max_light_bounces <= 7 (<= 5 with the extra draw per vertex of the REFLECTIVE and LAMBERT_IMP samplers);
      * bdpt_set_params refuses STRIDED with longer subpaths. */
     int32_t rng_mode;
     /* Which primitive the first light-subpath rays skip.  The reference reads
@@ -144,6 +160,9 @@ typedef struct bdpt_params {
     int32_t kernel_variant;     /* BDPT_KERNEL_* */
     int32_t sample_order;       /* BDPT_ORDER_* */
     int32_t sampler;            /* BDPT_SAMPLER_* */
+    float imp_light_weight;     /* lightWeight of brdf_lambertian_imp (0.0f in the call at kernel0.cl:945) */
+    float imp_half_angle;       /* halfAngle of brdf_lambertian_imp (0.2 * M_PI there) */
+    int32_t integrator;         /* BDPT_INTEGRATOR_* */
 } bdpt_params;
 
 typedef struct bdpt_ctx bdpt_ctx;

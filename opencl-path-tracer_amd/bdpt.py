@@ -31,7 +31,8 @@ FALLOFF_INV_SQ, FALLOFF_INV_SQ_PLUS_C = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_DUAL, KERNEL_LDS, KERNEL_TILED, KERNEL_LDS2 = 0, 1, 2, 3, 4, 5
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
-SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE = 0, 1, 2
+SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE, SAMPLER_LAMBERT_IMP = 0, 1, 2, 3
+INTEGRATOR_BIDIRECTIONAL, INTEGRATOR_PATH_TRACE = 0, 1
 AOV_EYE_HIT, AOV_HIT_HASH, AOV_RADIANCE, AOV_RNG_DRAWS, AOV_RAYS = 0, 1, 2, 3, 4
 QUERY_NOALLOC_MAX_RAYS = 65536   # BDPT_QUERY_NOALLOC_MAX_RAYS
 SCENE_CORNELL, SCENE_PLANES, SCENE_OUTDOOR, SCENE_SOUP = 0, 1, 2, 3
@@ -53,6 +54,9 @@ class Params(C.Structure):
         ("kernel_variant", C.c_int32),
         ("sample_order", C.c_int32),
         ("sampler", C.c_int32),
+        ("imp_light_weight", C.c_float),
+        ("imp_half_angle", C.c_float),
+        ("integrator", C.c_int32),
     ]
 
 

@@ -129,6 +129,9 @@ void bdpt_default_params(bdpt_params *p)
     p->kernel_variant = BDPT_KERNEL_AUTO;
     p->sample_order = BDPT_ORDER_AUTO;
     p->sampler = BDPT_SAMPLER_LAMBERT_CONE;
+    p->imp_light_weight = 0.0f;
+    p->imp_half_angle = (float)(0.2 * 3.14159265358979323846);
+    p->integrator = BDPT_INTEGRATOR_BIDIRECTIONAL;
 }
 
 int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
@@ -242,18 +245,22 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
     if ((p->sample_order == BDPT_ORDER_ROULETTE_CLASS || p->sample_order == BDPT_ORDER_ADAPTIVE) &&
         !(p->rng_mode == BDPT_RNG_STRIDED && p->accum_mode == BDPT_ACCUM_SUM))
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS / ADAPTIVE needs rng_mode STRIDED and accum_mode SUM");
-    if (p->sampler < BDPT_SAMPLER_LAMBERT_CONE || p->sampler > BDPT_SAMPLER_REFLECTIVE)
+    if (p->sampler < BDPT_SAMPLER_LAMBERT_CONE || p->sampler > BDPT_SAMPLER_LAMBERT_IMP)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sampler");
     if (p->sampler != BDPT_SAMPLER_LAMBERT_CONE && p->kernel_variant == BDPT_KERNEL_DUAL)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: the DUAL kernel variant has the LAMBERT_CONE sampler only");
+    if (p->integrator != BDPT_INTEGRATOR_BIDIRECTIONAL && p->integrator != BDPT_INTEGRATOR_PATH_TRACE)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown integrator");
+    if (p->integrator == BDPT_INTEGRATOR_PATH_TRACE && (p->rng_mode != BDPT_RNG_STREAM || p->accum_mode != BDPT_ACCUM_MEAN))
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: the PATH_TRACE integrator needs rng_mode STREAM and accum_mode MEAN");
     /* STRIDED spaces the samples of a pixel 32 generator outputs apart.  A sample draws 5 + per_vertex * maxL
      * numbers, the first of which is discarded (kernel0.cl:592, :106-109, :787): with more than 33 draws the
      * last numbers of sample s would be the first used numbers of sample s+1. */
     {
-        const int per_vertex = p->sampler == BDPT_SAMPLER_REFLECTIVE ? 5 : 4;
+        const int per_vertex = (p->sampler == BDPT_SAMPLER_REFLECTIVE || p->sampler == BDPT_SAMPLER_LAMBERT_IMP) ? 5 : 4;
         if (p->rng_mode == BDPT_RNG_STRIDED && 5 + per_vertex * p->max_light_bounces > 33)
             return fail(ctx, BDPT_ERR_INVALID,
-                        "bdpt_set_params: rng_mode STRIDED needs max_light_bounces <= 7 (<= 5 with the REFLECTIVE sampler): "
+                        "bdpt_set_params: rng_mode STRIDED needs max_light_bounces <= 7 (<= 5 with the REFLECTIVE and LAMBERT_IMP samplers): "
                         "longer light subpaths would reuse the random numbers of the next sample");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -613,6 +620,8 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.falloff_c = P.falloff_c;
     K.accum_mode = P.accum_mode;
     K.sampler = P.sampler;
+    K.imp_light_weight = P.imp_light_weight;
+    K.imp_half_angle = P.imp_half_angle;
     K.reorder = 0;
     if (P.rng_mode == BDPT_RNG_STRIDED && P.accum_mode == BDPT_ACCUM_SUM && P.sample_order != BDPT_ORDER_INDEX)
         K.reorder = P.sample_order == BDPT_ORDER_ROULETTE_CLASS ? 1 : 2;   /* AUTO and ADAPTIVE: decided per pixel */
@@ -647,7 +656,10 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         variant = (bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_TILED;
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
+    if (ctx->params.integrator == BDPT_INTEGRATOR_PATH_TRACE) {
+        variant = BDPT_KERNEL_DIRECT;
+        HIP_TRY(ctx, bdpt_launch_path_trace(K, aov, ctx->stream));
+    } else if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS2) HIP_TRY(ctx, bdpt_launch_lds2(K, aov, ctx->counters_on, ctx->stream));

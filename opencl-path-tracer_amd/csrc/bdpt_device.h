@@ -80,10 +80,23 @@ BDPT_DEV clm_f3 sample_hemisphere(uint32_t &w, uint32_t &draws, clm_f3 axis)
     return clm_mad3(sl, ring, clm_scale3(cl, axis));
 }
 
-/* the samplers other than the live one (kernel0.cl:767): hemisphere, or brdf_reflective :492-508 */
-BDPT_DEV clm_f3 sample_bounce_alt(const bdpt_kargs &K, uint32_t &w, uint32_t &draws, clm_f3 n, clm_f3 incoming)
+/* samplers that draw one number before the three of the cone */
+BDPT_DEV bool sampler_draws_four(int sampler)
+{
+    return sampler == BDPT_SAMPLER_REFLECTIVE || sampler == BDPT_SAMPLER_LAMBERT_IMP;
+}
+
+/* the samplers other than the live one (kernel0.cl:767): hemisphere, brdf_reflective :492-508, or
+ * brdf_lambertian_imp :512-543; `from` is the point the bounce ray leaves */
+BDPT_DEV clm_f3 sample_bounce_alt(const bdpt_kargs &K, uint32_t &w, uint32_t &draws, clm_f3 n, clm_f3 incoming, clm_f3 from)
 {
     if (K.sampler == BDPT_SAMPLER_HEMISPHERE) return sample_hemisphere(w, draws, n);
+    if (K.sampler == BDPT_SAMPLER_LAMBERT_IMP) {
+        const float p4 = rng_float(w, draws);                                        /* :513 */
+        const bool wide = p4 > K.imp_light_weight;                                   /* :517 */
+        const clm_f3 to_light = clm_normalize3(clm_sub3(f3(K.light_c), from));       /* the argument at :945 */
+        return sample_cone(w, draws, wide ? n : to_light, wide ? (float)(0.50f * CLM_PI_F64) : K.imp_half_angle);   /* :518-525 */
+    }
     const float p4 = rng_float(w, draws);                                            /* :493 */
     const bool mirror = p4 > 0.6f;                                                   /* :500 */
     const clm_f3 r = clm_reflect3(n, incoming);                                      /* :495 */
@@ -412,7 +425,7 @@ BDPT_DEV constexpr uint32_t lcg_pow(int e)
  * output number 9+4k: the start state times 48271^(9+4k). */
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
-    const bool five = K.sampler == BDPT_SAMPLER_REFLECTIVE;    /* one more draw per vertex: 10 + 5k */
+    const bool five = sampler_draws_four(K.sampler);           /* one more draw per vertex: 10 + 5k */
     const uint32_t step = five ? lcg_pow(5) : lcg_pow(4);
     int cls = K.max_l;
     uint32_t x = start_state * (five ? lcg_pow(10) : lcg_pow(9));

@@ -25,6 +25,9 @@ hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream
 /* The same work for scenes of any size: triangle records staged through wave-private LDS tiles. */
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
+/* The reference's older unidirectional kernel (kernel0.cl:872-1001): spp samples per pixel of the region in one launch. */
+hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream);
+
 /* Closest hit of n caller-supplied rays (6 floats each: origin, direction;
  * origin[2*i], origin[2*i+1] = primitive to skip or (4,0)). Device pointers. */
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

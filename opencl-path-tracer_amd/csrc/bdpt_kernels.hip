@@ -433,13 +433,13 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
          * consumes a fixed number of draws: step over them, draw the fate, and build the direction
          * from the stepped-over numbers only when it is needed. */
         uint32_t w_dir = w, draws_dir = 0;
-        const bool four = ALT && K.sampler == BDPT_SAMPLER_REFLECTIVE;
+        const bool four = ALT && sampler_draws_four(K.sampler);
         w *= four ? lcg_pow(4) : lcg_pow(3);
         draws += four ? 4u : 3u;
         float fate = rng_float(w, draws);                                 /* :787 */
         if (fate > K.p_con) break;                                        /* :788 */
         if (!ALL_RAYS && lti + 1 == K.max_l) break;                       /* nothing reads what the last bounce ray finds */
-        clm_f3 ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming)
+        clm_f3 ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming, lpos)
                           : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
 
         Hit nxt = trace_one<MODE, true, COUNT>(S, lpos, ldir, vtype, vidx, T);   /* :793 */
@@ -839,14 +839,14 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
             lpos = clm_mad3(0.00001f, vn, vpos);                          /* :761 */
             /* as in sample_direct: the fate first, the direction only for the lanes that go on */
             uint32_t w_dir = w, draws_dir = 0;
-            const bool four = ALT && K.sampler == BDPT_SAMPLER_REFLECTIVE;
+            const bool four = ALT && sampler_draws_four(K.sampler);
             w *= four ? lcg_pow(4) : lcg_pow(3);
             draws += four ? 4u : 3u;
             const float fate = rng_float(w, draws);                       /* :787 */
             if (fate > K.p_con) alive = false;                            /* :788 */
             if (!ALL_RAYS && lti + 1 == K.max_l) alive = false;           /* nothing reads what the last bounce ray finds */
             if (alive)
-                ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming)
+                ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming, lpos)
                            : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
         }
         pre *= K.p_con;                                                   /* :745 */
@@ -976,6 +976,97 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
         atomicAdd(&K.counters[2], c_early);
         atomicAdd(&K.counters[3], c_cull);
         atomicAdd(&K.counters[4], c_exact);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* path_trace, kernel0.cl:872-1001: the unidirectional kernel the reference's file
+ * keeps commented out.  One lane per pixel, spp samples per launch as that
+ * kernel's own sample loop (:908) runs them; the plain walk over the primitives.  */
+/* ------------------------------------------------------------------------- */
+
+template <bool AOV>
+__global__ __launch_bounds__(BDPT_BLOCK) void bdpt_path_trace_kernel(const bdpt_kargs K)
+{
+    int x, y;
+    lane_pixel(K, x, y);
+    if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
+    const size_t pix = (size_t)y * K.width + x;
+    const bdpt_dev_scene &S = K.scene;
+    float4 a4 = K.accum[pix];
+    float prev[4] = {a4.x, a4.y, a4.z, a4.w};                             /* :887 */
+    uint32_t w = K.seed_w[pix];                                           /* :890 */
+    uint32_t draws = 0, rays = 0, hash = 0;
+    if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
+    int eye_id[2] = {-1, -1};
+    float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    rng_float(w, draws);                                                  /* :892, discarded; once per launch */
+    float xt, yt;
+    pixel_coord(K, x, y, xt, yt);                                         /* :899-903 */
+    const float wt_brdf = (float)((double)0.5f * CLM_1_PI_F64);           /* launchDir.w, :505 */
+    const float inv_2pi = (float)CLM_1_PI_F64 * 0.5f;                     /* (float)M_1_PI * 0.5f, :971 */
+    for (int k = 0; k < K.spp; k++) {                                     /* :908 */
+        const int n = K.num_samples + k;
+        clm_f3 vdir = camera_ray(w, draws, K, xt, yt);                    /* :910-912; eyePatch.vDir :920 */
+        clm_f3 vpos = f3(K.cam_pos);                                      /* :921 */
+        int vtype = -1, vidx = -1;                                        /* :922-923 */
+        col[0] = col[1] = col[2] = col[3] = 1.0f;                         /* :925 */
+        clm_f3 incoming = clm_make3(0.0f, 0.0f, 0.0f);                    /* :930 */
+        for (int i = 0; i < 5; i++) {                                     /* :932 */
+            const clm_f3 lpos = clm_mad3(0.00001f, vdir, vpos);           /* :936 */
+            /* brdf_reflective (:943, :492-508): p4, then a cone about the mirror direction or about the normal */
+            const float p4 = rng_float(w, draws);
+            const bool mirror = p4 > 0.6f;
+            const clm_f3 axis = mirror ? clm_reflect3(vdir, incoming) : vdir;
+            clm_f3 ldir = sample_cone(w, draws, axis, mirror ? 3.1415f * 0.02f : 3.1415f * 0.50f);
+            float wt = wt_brdf;                                           /* :947 */
+            if (i == 0) { wt = 1.0f; ldir = vdir; }                       /* :951-954 */
+            if (i == 4) {                                                 /* :956-959 */
+#pragma unroll
+                for (int c = 0; c < 4; c++) col[c] *= 0.3f;
+                break;
+            }
+            const Hit h = closest_hit_direct(S, lpos, ldir, vtype, vidx); /* :964 */
+            rays++;
+            if (AOV) {
+                hash = hash_step(hash, hit_id(h.type, h.idx));
+                if (i == 0) { eye_id[0] = h.type; eye_id[1] = h.idx; }
+            }
+            incoming = ldir;                                              /* :966 */
+            if (h.type < 0) {                                             /* :978-982 */
+                col[0] *= 0.3f; col[1] *= 0.3f; col[2] *= 0.4f; col[3] *= 0.3f;
+                break;
+            }
+            const float4 sd = S.surf[h.surf * 2], se = S.surf[h.surf * 2 + 1];
+            if (se.w != 0.0f) {                                           /* :969-974: (emissive / wt) * (M_1_PI * 0.5f) */
+                col[0] *= clm_div(se.x, wt) * inv_2pi; col[1] *= clm_div(se.y, wt) * inv_2pi;
+                col[2] *= clm_div(se.z, wt) * inv_2pi; col[3] *= clm_div(se.w, wt) * inv_2pi;
+                break;
+            }
+            const float m1pi = (float)CLM_1_PI_F64;                       /* :976: ((diffuse / wt) * M_1_PI) * 0.5f */
+            col[0] *= clm_div(sd.x, wt) * m1pi * 0.5f; col[1] *= clm_div(sd.y, wt) * m1pi * 0.5f;
+            col[2] *= clm_div(sd.z, wt) * m1pi * 0.5f; col[3] *= clm_div(sd.w, wt) * m1pi * 0.5f;
+            vpos = h.pos; vdir = h.n; vtype = h.type; vidx = h.idx;       /* :984 */
+        }
+        if (n == 0) {                                                     /* :991-992 */
+#pragma unroll
+            for (int c = 0; c < 4; c++) prev[c] = col[c];
+        } else {                                                          /* :990 */
+            const float s1 = clm_div((float)n, (float)(n + 1));
+            const float s2 = clm_div(1.0f, (float)(n + 1));
+#pragma unroll
+            for (int c = 0; c < 4; c++) prev[c] = clm_fma(col[c], s2, prev[c] * s1);
+        }
+    }
+    K.seed_w[pix] = w;                                                    /* :998 */
+    K.accum[pix] = make_float4(prev[0], prev[1], prev[2], prev[3]);       /* :1000 */
+    if (AOV) {
+        K.aov_eye_hit[pix * 2] = eye_id[0];
+        K.aov_eye_hit[pix * 2 + 1] = eye_id[1];
+        K.aov_hit_hash[pix] = hash;
+        K.aov_radiance[pix] = make_float4(col[0], col[1], col[2], col[3]);
+        K.aov_rng_draws[pix] = draws;
+        K.aov_rays[pix] = rays;
     }
 }
 
@@ -1110,6 +1201,16 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
         else BDPT_LAUNCH(false, false, false);
     }
 #undef BDPT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    if (grid.x == 0) return hipSuccess;
+    if (aov) hipLaunchKernelGGL(bdpt::bdpt_path_trace_kernel<true>, grid, block, 0, stream, K);
+    else hipLaunchKernelGGL(bdpt::bdpt_path_trace_kernel<false>, grid, block, 0, stream, K);
     return hipGetLastError();
 }
 

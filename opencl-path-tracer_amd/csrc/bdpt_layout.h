@@ -101,6 +101,7 @@ struct bdpt_kargs {
     float falloff_c;
     int accum_mode;
     int sampler;                /* BDPT_SAMPLER_* */
+    float imp_light_weight, imp_half_angle;   /* brdf_lambertian_imp's lightWeight and halfAngle */
     /* STRIDED + SUM launches take the samples of a pixel grouped by the length Russian roulette
      * gives their light subpath (see SampleCursor in bdpt_device.h) */
     int reorder;                /* 0 index order, 1 roulette classes, 2 roulette classes for the pixels whose first eye ray reaches a surface */

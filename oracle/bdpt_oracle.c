@@ -132,6 +132,24 @@ static clm_f3 brdf_reflective(Lane *L, clm_f3 normal, clm_f3 vDir)
     return random_sample_cone(L, normal, 3.1415f * 0.50f);              /* :503 */
 }
 
+/* ---- brdf_lambertian_imp, kernel0.cl:512-543 -------------------------------- */
+/* Only the direction: the density it also returns in .w (:527-540) is zeroed unread by the live kernel (:772-778). */
+
+static clm_f3 brdf_lambertian_imp(Lane *L, clm_f3 normal, clm_f3 vDirLight, float lightWeight, float halfAngle)
+{
+    float p4 = get_rng_float(L);                                        /* :513 */
+    clm_f3 dir;
+    float angle;
+    if (p4 > lightWeight) {                                             /* :517 */
+        dir = normal;                                                   /* :518 */
+        angle = (float)((double)0.50f * CLM_PI_F64);                    /* :519, fp64 product narrowed by the assignment */
+    } else {
+        dir = vDirLight;                                                /* :521 */
+        angle = halfAngle;                                              /* :522 */
+    }
+    return random_sample_cone(L, dir, angle);                           /* :525 */
+}
+
 /* ---- findRandomPoint, kernel0.cl:190-202 ----------------------------------- */
 
 static void findRandomPoint(Lane *L, float blur, int W, int H, float pixx, float pixy,
@@ -435,6 +453,9 @@ static Sample trace_sample(Lane *L, const orc_job *J, const Scene *sc, int x, in
         clm_f3 launchDir;
         if (P->sampler == BDPT_SAMPLER_HEMISPHERE) launchDir = random_sample_hemisphere(L, launchRef);
         else if (P->sampler == BDPT_SAMPLER_REFLECTIVE) launchDir = brdf_reflective(L, launchRef, incomingDir);
+        else if (P->sampler == BDPT_SAMPLER_LAMBERT_IMP)                  /* the call at :945, aimed at the light's centre */
+            launchDir = brdf_lambertian_imp(L, launchRef, clm_normalize3(clm_sub3(v3(lsph->center), launchPos)),
+                                            P->imp_light_weight, P->imp_half_angle);
         else launchDir = random_sample_cone(L, launchRef, 3.1415f * 0.50f);   /* :767, :486 */
 
         float fate = get_rng_float(L);                                    /* :787 */
@@ -462,6 +483,106 @@ static Sample trace_sample(Lane *L, const orc_job *J, const Scene *sc, int x, in
     return S;
 }
 
+/* ---- path_trace, kernel0.cl:872-1001 (commented out in the reference): ONE sample of its loop :908-996 ---- */
+
+static Sample path_trace_sample(Lane *L, const orc_job *J, const Scene *sc, float xt, float yt)
+{
+    const bdpt_params *P = J->params;
+    const bdpt_camera *cam = J->camera;
+    Sample S;
+    memset(&S, 0, sizeof S);
+    S.eye_type = S.eye_index = -1;
+
+    float sx, sy;
+    findRandomPoint(L, P->blur_factor, J->width, J->height, xt, yt, &sx, &sy);   /* :910 */
+    clm_f3 ray = shoot_ray(sx, sy, cam);                                  /* :912 */
+
+    Full patch;                                                           /* eyePatch, :919-923, :928 */
+    memset(&patch, 0, sizeof patch);
+    patch.n = ray;
+    patch.k.pos = v3(cam->pos);
+    patch.type = -1;
+    patch.index = -1;
+
+    float col[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :925 */
+    clm_f3 incomingDir = clm_make3(0.0f, 0.0f, 0.0f);                     /* :930 */
+    for (int i = 0; i < 5; i++) {                                         /* :932 */
+        clm_f3 launchRef = patch.n;                                       /* :935 */
+        clm_f3 launchPos = clm_mad3(0.00001f, patch.n, patch.k.pos);      /* :936 */
+        clm_f3 launchDir = brdf_reflective(L, patch.n, incomingDir);      /* :943 */
+        float wt = (float)((double)0.5f * CLM_1_PI_F64);                  /* :947, launchDir.w of :505 */
+        if (i == 0) {                                                     /* :951-954 */
+            wt = 1.0f;
+            launchDir = launchRef;
+        }
+        if (i == 4) {                                                     /* :956-959 */
+            for (int k = 0; k < 4; k++) col[k] *= 0.3f;
+            break;
+        }
+        Full patch2 = ray_intersect(L, sc, launchPos, launchDir, patch.type, patch.index);   /* :964 */
+        if (i == 0) { S.eye_type = patch2.type; S.eye_index = patch2.index; }
+        incomingDir = launchDir;                                          /* :966 */
+        if (patch2.k.hit) {                                               /* :968 */
+            if (patch2.emissive[3] != 0.0f) {                             /* :969-974 */
+                for (int k = 0; k < 4; k++)
+                    col[k] *= clm_div(patch2.emissive[k], wt) * ((float)CLM_1_PI_F64 * 0.5f);
+                break;
+            }
+            for (int k = 0; k < 4; k++)                                   /* :976 */
+                col[k] *= clm_div(patch2.diffuse[k], wt) * (float)CLM_1_PI_F64 * 0.5f;
+        } else {                                                          /* :978-982 */
+            col[0] *= 0.3f; col[1] *= 0.3f; col[2] *= 0.4f; col[3] *= 0.3f;
+            break;
+        }
+        patch = patch2;                                                   /* :984 */
+    }
+    copy4(S.col, col);                                                    /* :989 */
+    return S;
+}
+
+/* One launch of path_trace with sampleRate = spp for one pixel (:884-1000). */
+static void path_trace_pixel(orc_job *J, const Scene *sc, int x, int y, uint64_t cnt[3])
+{
+    const int W = J->width, H = J->height;
+    const size_t pix = (size_t)y * W + x;
+    const size_t sidx = ((size_t)x * H + y) * 4 + 3;                      /* :890 */
+    Lane L;
+    L.draws = J->aov_rng_draws ? J->aov_rng_draws[pix] : 0;
+    L.rays = J->aov_rays ? J->aov_rays[pix] : 0;
+    L.hash = J->aov_hit_hash ? J->aov_hit_hash[pix] : 0;
+    L.w = J->seeds[sidx];
+    float *acc = &J->accum[pix * 4];                                      /* prevValue, :887 */
+    rng_next(&L);                                                         /* :892 */
+    float xf = clm_div((float)x, (float)W * 1.0f);                        /* :899 */
+    float yf = clm_div((float)y, (float)H * 1.0f);                        /* :900 */
+    float aspect = clm_div((float)W * 1.0f, (float)H);
+    float xt = (float)(((double)xf * 2.0 - (double)1.0f) * (double)aspect);   /* :902 */
+    float yt = (float)((double)yf * 2.0 - (double)1.0f);                  /* :903 */
+    Sample S;
+    memset(&S, 0, sizeof S);
+    S.eye_type = S.eye_index = -1;
+    for (int k = 0; k < J->spp; k++) {                                    /* :908 */
+        const int n = J->num_samples + k;
+        uint32_t rays0 = L.rays;
+        S = path_trace_sample(&L, J, sc, xt, yt);
+        cnt[0] += L.rays - rays0;
+        cnt[1]++;
+        if (n == 0) {                                                     /* :991-992 */
+            for (int c = 0; c < 4; c++) acc[c] = S.col[c];
+        } else {                                                          /* :990 */
+            float s1 = clm_div((float)n, (float)(n + 1));
+            float s2 = clm_div(1.0f, (float)(n + 1));
+            for (int c = 0; c < 4; c++) acc[c] = clm_fma(S.col[c], s2, acc[c] * s1);
+        }
+    }
+    J->seeds[sidx] = L.w;                                                 /* :998 */
+    if (J->aov_eye_hit) { J->aov_eye_hit[pix * 2] = S.eye_type; J->aov_eye_hit[pix * 2 + 1] = S.eye_index; }
+    if (J->aov_radiance) for (int k = 0; k < 4; k++) J->aov_radiance[pix * 4 + k] = S.col[k];
+    if (J->aov_hit_hash) J->aov_hit_hash[pix] = L.hash;
+    if (J->aov_rng_draws) J->aov_rng_draws[pix] = L.draws;
+    if (J->aov_rays) J->aov_rays[pix] = L.rays;
+}
+
 /* LCG multiplier for one sample's stride in STRIDED mode: 48271^32 mod 2^32 */
 static uint32_t pow_u32(uint32_t base, uint32_t e)
 {
@@ -479,7 +600,7 @@ static uint32_t pow_u32(uint32_t base, uint32_t e)
  * reflective sampler's extra draw per vertex -- and depend on nothing else). */
 static int roulette_class(const bdpt_params *P, uint32_t start_state)
 {
-    const int per_vertex = P->sampler == BDPT_SAMPLER_REFLECTIVE ? 5 : 4;   /* draws from one roulette draw to the next */
+    const int per_vertex = (P->sampler == BDPT_SAMPLER_REFLECTIVE || P->sampler == BDPT_SAMPLER_LAMBERT_IMP) ? 5 : 4;   /* draws from one roulette draw to the next */
     uint32_t w = start_state;
     for (int j = 0; j < 5 + per_vertex; j++) w *= 48271u;
     for (int k = 0; k + 1 < P->max_light_bounces; k++) {
@@ -575,7 +696,8 @@ int orc_render(orc_job *J)
 #endif
     for (int i = 0; i < npix; i++) {
         uint64_t cnt[3] = {0, 0, 0};
-        render_pixel(J, &sc, J->x0 + i % J->w, J->y0 + i / J->w, cnt);
+        if (J->params->integrator == BDPT_INTEGRATOR_PATH_TRACE) path_trace_pixel(J, &sc, J->x0 + i % J->w, J->y0 + i / J->w, cnt);
+        else render_pixel(J, &sc, J->x0 + i % J->w, J->y0 + i / J->w, cnt);
         c0 += cnt[0]; c1 += cnt[1]; c2 += cnt[2];
     }
     J->counters[0] = c0; J->counters[1] = c1; J->counters[2] = c2;

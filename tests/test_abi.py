@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_reference_host_structs(bdpt):
     assert bdpt.triangle_dtype.itemsize == 64 and bdpt.triangle_dtype.fields["surface"][1] == 48
     assert bdpt.plane_dtype.itemsize == 48 and bdpt.plane_dtype.fields["surface"][1] == 32
     assert bdpt.surface_dtype.itemsize == 32 and bdpt.camera_dtype.itemsize == 48
-    assert C.sizeof(bdpt.Params) == 56
+    assert C.sizeof(bdpt.Params) == 68
 
 
 def test_default_params_are_the_reference_literals(bdpt):

@@ -296,13 +296,14 @@ def test_sample_orders_take_the_same_samples(bdpt, oracle, variant, p_continue, 
 
 
 @pytest.mark.parametrize("variant", [1, 3, 4, 5])
-@pytest.mark.parametrize("sampler", [1, 2])
+@pytest.mark.parametrize("sampler", [1, 2, 3])
 def test_alternative_samplers_match_the_oracle(bdpt, oracle, variant, sampler):
-    """HEMISPHERE and REFLECTIVE bounce samplers: per-sample parity in STREAM mode and a class-ordered STRIDED + SUM
+    """HEMISPHERE, REFLECTIVE and LAMBERT_IMP bounce samplers: per-sample parity in STREAM mode and a class-ordered STRIDED + SUM
     launch, on every kernel variant that has them."""
     scene = bdpt.Scene.cornell()
     W, H = 48, 40
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=41, kernel_variant=variant, sampler=sampler)
+    extra = dict(imp_light_weight=0.4) if sampler == 3 else {}      # both branches of brdf_lambertian_imp
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=41, kernel_variant=variant, sampler=sampler, **extra)
     for s in range(6):
         ctx.render(1)
         oracle.render(st, scene, scene.camera, p, 1, n_threads=8)
@@ -312,11 +313,29 @@ def test_alternative_samplers_match_the_oracle(bdpt, oracle, variant, sampler):
     _compare(bdpt, ctx, st, "sampler %d batch:" % sampler)
     ctx.close()
     ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=43, kernel_variant=variant, sampler=sampler,
-                       rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+                       rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, **extra)
     ctx.render(45)
     oracle.render(st, scene, scene.camera, p, 45, n_threads=8)
     _compare(bdpt, ctx, st, "sampler %d strided sum:" % sampler)
     ctx.close()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "outdoor", "cornell_planes"])
+def test_path_trace_integrator_matches_the_oracle(bdpt, oracle, scene_name):
+    """The unidirectional kernel the reference keeps commented out (kernel0.cl:872-1001): launches of 1, 3 and 6
+    samples (one discarded draw per launch, as its sample loop has it), every parity output and the image."""
+    scene = getattr(bdpt.Scene, scene_name)()
+    W, H = 72, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=51, integrator=bdpt.INTEGRATOR_PATH_TRACE)
+    for spp in (1, 3, 6):
+        ctx.render(spp)
+        oracle.render(st, scene, scene.camera, p, spp, n_threads=8)
+        _compare(bdpt, ctx, st, "path_trace %s spp %d:" % (scene_name, spp))
+    assert ctx.num_samples == 10
+    ctx.close()
+    with bdpt.Context(16, 16) as c2:
+        with pytest.raises(bdpt.BdptError, match="PATH_TRACE"):
+            c2.set_params(bdpt.default_params(integrator=bdpt.INTEGRATOR_PATH_TRACE, rng_mode=bdpt.RNG_STRIDED))
 
 
 def test_dual_variant_has_only_the_live_sampler(bdpt):
@@ -410,10 +429,10 @@ def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
     for case in range(24):
         spp = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 65, 97, 150]))
         kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, max_light_bounces=int(rng.integers(1, 10)),
-                  p_continue=float(rng.uniform(0.05, 0.97)), sampler=int(rng.choice([0, 0, 1, 2])),
+                  p_continue=float(rng.uniform(0.05, 0.97)), sampler=int(rng.choice([0, 0, 1, 2, 3])),
                   kernel_variant=int(rng.choice([0, 1, 3, 4, 5])))
         # STRIDED keeps the samples of a pixel 32 draws apart: at most 7 vertices (5 with the REFLECTIVE sampler)
-        kw["max_light_bounces"] = min(kw["max_light_bounces"], 5 if kw["sampler"] == 2 else 7)
+        kw["max_light_bounces"] = min(kw["max_light_bounces"], 5 if kw["sampler"] >= 2 else 7)
         offset = int(rng.integers(0, 5000))
         ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=100 + case, **kw)
         ctx.set_sample_offset(offset)

@@ -492,3 +492,31 @@ def test_region_golden(bdpt, oracle, case):
     assert np.array_equal(crop(st.eye_hit), g["out_eye_hit"][s]) and np.array_equal(crop(st.hit_hash), g["out_hit_hash"][s])
     assert np.array_equal(crop(st.rng_draws), g["out_rng_draws"][s]) and np.array_equal(crop(st.rays), g["out_rays"][s])
     assert np.array_equal(crop(st.accum).view(np.uint32), g["out_accum"][s].view(np.uint32))
+
+
+def test_path_trace_sky_and_light_known_answers(bdpt, oracle):
+    """path_trace (kernel0.cl:872-1001): an eye ray that leaves the scene returns the sky colour of :979, one that
+    sees the light its emission / (2 pi) (:971 with wt = 1), and every sample draws 2 + 4 numbers per loop pass."""
+    scene = bdpt.Scene.outdoor()
+    W, H = 64, 36
+    p = bdpt.default_params(aov_enable=1, integrator=bdpt.INTEGRATOR_PATH_TRACE)
+    st = oracle.State(W, H, bdpt.make_seeds(W, H, 3))
+    oracle.render(st, scene, scene.camera, p, 1, n_threads=4)
+    miss = st.eye_hit[..., 0] < 0
+    assert miss.any() and (~miss).any()
+    assert np.array_equal(st.radiance[miss], np.tile(np.float32([0.3, 0.3, 0.4, 0.3]), (miss.sum(), 1)))
+    assert (st.rays[miss] == 1).all() and (st.rng_draws[miss] == 1 + 2 + 4).all()
+    light = (st.eye_hit[..., 0] == 0) & (st.eye_hit[..., 1] == 0)
+    if light.any():
+        e = scene.surfaces["emissive"][scene.spheres["surface"][0]]
+        np.testing.assert_allclose(st.radiance[light], np.tile(e / np.float32(2 * np.pi), (light.sum(), 1)), rtol=1e-6)
+    # four rays: either the fourth ended the path (2 + 4*4 draws) or the fifth vertex was reached, whose sampler
+    # still draws before the loop ends with the factor 0.3 of :957 (2 + 5*4 draws)
+    deep = st.rays == 4
+    assert deep.any() and set(np.unique(st.rng_draws[deep])) <= {1 + 2 + 16, 1 + 2 + 20}
+    # a second launch discards one more draw (:892) and blends with the running mean (:990)
+    before = st.accum.copy()
+    oracle.render(st, scene, scene.camera, p, 1, n_threads=4)
+    both = miss & (st.eye_hit[..., 0] < 0)          # sky in both samples (a silhouette pixel may hit the second time)
+    np.testing.assert_allclose(st.accum[both], before[both], rtol=1e-6)
+    assert (st.rng_draws[both] == 2 * (1 + 2 + 4)).all()

@@ -14,6 +14,7 @@ RMSE_BOUND = 0.02      # on linear RGB clamped to [0,1]: the converged-image bar
 
 
 def _rmse(a, b):
+    """Root-mean-square difference of linear RGB clamped to [0,1]; a, b are [..., 4] arrays of the same pixels."""
     a = np.clip(a[..., :3], 0, 1).astype(np.float64)
     b = np.clip(b[..., :3], 0, 1).astype(np.float64)
     return float(np.sqrt(np.mean((a - b) ** 2)))
@@ -31,20 +32,65 @@ def _render(bdpt, scene, W, H, spp, seed, **params):
     return img, ms
 
 
+def _frozen(bdpt, ctx, W, H):
+    """Pixels whose generator word no longer advances in STREAM mode: a sample of theirs returned at the eye ray, the
+    reference then writes the raw value and skips the seed write-back (kernel0.cl:645-656), so every later sample
+    repeats that one.  Found by rendering one more sample and comparing the seeds."""
+    before = ctx.read_seeds()
+    ctx.render(1)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    idx = (xs * H + ys) * 4 + 3
+    return before[idx] == ctx.read_seeds()[idx]
+
+
 def test_converged_images_agree_across_generator_modes_and_seeds(bdpt):
-    """STREAM (the reference's sequence) and STRIDED (the counter-addressed sequence used to split samples
-    across GPUs) are different sample sets of the same estimator: at 16384 spp they agree to RMSE < 0.02."""
+    """STREAM (the reference's sequence) and STRIDED (the counter-addressed sequence used to split samples across
+    GPUs) are different sample sets of the same estimator.  At 16384 spp they agree to RMSE < 0.02 on linear RGB
+    clamped to [0,1], over the whole frame and over the pixels that are not frozen in STREAM mode.  The residual is
+    not 1/sqrt(N) noise: the connection term 1/r^2 (kernel0.cl:719) is unbounded, so single samples can outweigh
+    thousands (the reference's README calls them fireflies) and the error falls slower than 1/sqrt(N)."""
     scene = bdpt.Scene.cornell()
     W, H, SPP = 128, 72, 16384
-    stream, _ = _render(bdpt, scene, W, H, SPP, 0x5EED)
+
+    def stream(seed):
+        with bdpt.Context(W, H) as ctx:
+            ctx.upload_scene(scene)
+            ctx.upload_seeds(bdpt.make_seeds(W, H, seed))
+            ctx.set_camera(scene.camera)
+            ctx.render(SPP)
+            img = ctx.read_accum()
+            return img, _frozen(bdpt, ctx, W, H)
+
+    a, frozen_a = stream(0x5EED)
+    b, frozen_b = stream(0xBEEF)
     strided, _ = _render(bdpt, scene, W, H, SPP, 0x5EED, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
     strided = strided / SPP
-    other, _ = _render(bdpt, scene, W, H, SPP, 0xBEEF)
-    # pixels whose first stream-mode sample returned early are frozen at that value (kernel0.cl:645-656)
-    # while STRIDED averages over the pixel footprint; they only occur on silhouettes
-    assert _rmse(stream, strided) < RMSE_BOUND
-    assert _rmse(stream, other) < RMSE_BOUND
-    assert np.isfinite(stream).all() and stream[..., :3].mean() > 0.05
+    assert _rmse(a, strided) < RMSE_BOUND and _rmse(a, b) < RMSE_BOUND
+    live = ~frozen_a & ~frozen_b
+    assert 0.4 < live.mean() < 0.9                      # the black surround is frozen from the first sample on
+    assert _rmse(a[live], strided[live]) < RMSE_BOUND and _rmse(a[live], b[live]) < RMSE_BOUND
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0.05
+
+
+def test_converged_image_agrees_with_the_oracle(bdpt):
+    """The one RMSE check that is parity and not GPU against GPU: the GPU's 16384-spp STRIDED image against a
+    2048-spp STREAM render of the CPU oracle with other seeds.  Bound 0.02 as above; and the oracle's image is as far
+    from the GPU's converged image as a GPU image of the same 2048 spp with yet other seeds is (within 25 %), i.e.
+    the two are samples of one estimator."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_bind as oracle
+
+    scene = bdpt.Scene.cornell()
+    W, H = 128, 72
+    conv, _ = _render(bdpt, scene, W, H, 16384, 0x5EED, rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    conv = conv / 16384
+    st = oracle.State(W, H, bdpt.make_seeds(W, H, 0xC0DE))
+    oracle.render(st, scene, scene.camera, bdpt.default_params(), 2048, n_threads=16)
+    gpu2048, _ = _render(bdpt, scene, W, H, 2048, 0xD00D)
+    e_oracle, e_gpu = _rmse(conv, st.accum), _rmse(conv, gpu2048)
+    assert e_oracle < RMSE_BOUND and e_gpu < RMSE_BOUND
+    assert abs(e_oracle - e_gpu) < 0.25 * e_gpu, (e_oracle, e_gpu)
 
 
 def test_full_frame_properties_at_benchmark_size(bdpt):

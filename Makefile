@@ -16,7 +16,7 @@ HOSTBIN  := $(PKG)/bdpt_host
 ORACLE   := oracle/libbdpt_oracle.so
 ORACLE_NOFMA := oracle/libbdpt_oracle_nofma.so
 
-LIB_SRCS := $(CSRC)/bdpt_api.cpp $(CSRC)/bdpt_kernels.hip
+LIB_SRCS := $(CSRC)/bdpt_api.cpp $(CSRC)/bdpt_group.cpp $(CSRC)/bdpt_kernels.hip
 LIB_DEPS := $(LIB_SRCS) $(wildcard $(CSRC)/*.h) include/bdpt.h include/bdpt_clmath.h
 
 HOSTLIB  := $(PKG)/libbdpt_host.so
@@ -35,7 +35,7 @@ $(HOSTBIN): $(PKG)/host/main.cpp $(HOSTLIB)
 	$(CXX) $(CXXFLAGS) $(PKG)/host/main.cpp -o $@ -L$(PKG) -lbdpt_host -lbdpt_amd -Wl,-rpath,'$$ORIGIN'
 
 $(LIB): $(LIB_DEPS)
-	$(HIPCC) $(HIPFLAGS) -shared -x hip $(LIB_SRCS) -o $@
+	$(HIPCC) $(HIPFLAGS) -shared -x hip $(LIB_SRCS) -o $@ -ldl
 
 # -mfma: fmaf() becomes one instruction; the no-FMA build calls libm's fmaf(),
 # which rounds identically, for hosts without the instruction.

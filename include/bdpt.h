@@ -304,6 +304,34 @@ int bdpt_last_launch_variant(const bdpt_ctx *ctx);
  * the stream the kernel ran on); waits for that launch. */
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms);
 
+/* ---- several GPUs of one node behind one handle ---------------------------
+ * The reference drives one device (main.cpp:242-260, :522).  A group holds one context per GPU, in one
+ * process, driven by the calling thread: uploads and camera changes go to every member, a render call
+ * deals the samples of each pixel to the members (rng_mode STRIDED + accum_mode SUM, set by the group and
+ * required of bdpt_group_set_params), and bdpt_group_read_image sums the members' partial images on member
+ * 0 -- one RCCL reduce over xGMI (BDPT_COMBINE_RCCL; the library is looked up at run time), or
+ * device-to-device copies and an add kernel (BDPT_COMBINE_COPY; also what a group that names one GPU
+ * twice uses) -- and returns the mean.  BDPT_COMBINE_AUTO takes RCCL when it loads.  A render call of spp
+ * samples gives member r the sample indices [N + r*spp/n, ...) after the N rendered since the last camera
+ * change, so the image depends on spp and on the number of GPUs only through the order of float additions.
+ * Errors: as for contexts, message through bdpt_group_last_error. */
+typedef struct bdpt_group bdpt_group;
+enum { BDPT_COMBINE_AUTO = 0, BDPT_COMBINE_RCCL = 1, BDPT_COMBINE_COPY = 2 };
+int bdpt_group_create(const int *device_ordinals, int n_devices, int width, int height, int combine, bdpt_group **out);
+void bdpt_group_destroy(bdpt_group *g);
+const char *bdpt_group_last_error(const bdpt_group *g);
+int bdpt_group_size(const bdpt_group *g);
+bdpt_ctx *bdpt_group_member(bdpt_group *g, int i);      /* for queries (bdpt_last_launch_ms, ...); owned by the group */
+int bdpt_group_combine(const bdpt_group *g);            /* BDPT_COMBINE_RCCL or BDPT_COMBINE_COPY: what read_image uses */
+int bdpt_group_set_params(bdpt_group *g, const bdpt_params *p);
+int bdpt_group_upload_scene(bdpt_group *g, const bdpt_sphere *spheres, int n_spheres, const bdpt_plane *planes, int n_planes,
+                            const bdpt_triangle *triangles, int n_triangles, const bdpt_surface *surfaces, int n_surfaces);
+int bdpt_group_upload_seeds(bdpt_group *g, const uint32_t *seeds);
+int bdpt_group_set_camera(bdpt_group *g, const bdpt_camera *cam);       /* also zeroes the sample counters */
+int bdpt_group_render(bdpt_group *g, int spp);                          /* spp more samples per pixel, all members together; waits */
+int bdpt_group_num_samples(const bdpt_group *g);
+int bdpt_group_read_image(bdpt_group *g, float *rgba);                  /* mean image, width*height RGBA float, row-major */
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,7 @@ ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
 SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE, SAMPLER_LAMBERT_IMP = 0, 1, 2, 3
 INTEGRATOR_BIDIRECTIONAL, INTEGRATOR_PATH_TRACE = 0, 1
 AOV_EYE_HIT, AOV_HIT_HASH, AOV_RADIANCE, AOV_RNG_DRAWS, AOV_RAYS = 0, 1, 2, 3, 4
+COMBINE_AUTO, COMBINE_RCCL, COMBINE_COPY = 0, 1, 2
 QUERY_NOALLOC_MAX_RAYS = 65536   # BDPT_QUERY_NOALLOC_MAX_RAYS
 SCENE_CORNELL, SCENE_PLANES, SCENE_OUTDOOR, SCENE_SOUP = 0, 1, 2, 3
 
@@ -115,6 +116,23 @@ lib.bdpt_query_rays.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
 lib.bdpt_query_rays_noalloc.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
 lib.bdpt_clmath_eval.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int]
 lib.bdpt_last_launch_ms.argtypes = [_vp, C.POINTER(C.c_float)]
+
+lib.bdpt_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
+lib.bdpt_group_destroy.argtypes = [_vp]
+lib.bdpt_group_destroy.restype = None
+lib.bdpt_group_last_error.argtypes = [_vp]
+lib.bdpt_group_last_error.restype = C.c_char_p
+lib.bdpt_group_size.argtypes = [_vp]
+lib.bdpt_group_member.argtypes = [_vp, C.c_int]
+lib.bdpt_group_member.restype = _vp
+lib.bdpt_group_combine.argtypes = [_vp]
+lib.bdpt_group_set_params.argtypes = [_vp, C.POINTER(Params)]
+lib.bdpt_group_upload_scene.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]
+lib.bdpt_group_upload_seeds.argtypes = [_vp, _vp]
+lib.bdpt_group_set_camera.argtypes = [_vp, _vp]
+lib.bdpt_group_render.argtypes = [_vp, C.c_int]
+lib.bdpt_group_num_samples.argtypes = [_vp]
+lib.bdpt_group_read_image.argtypes = [_vp, _vp]
 
 hostlib.bdpt_host_scene_create.restype = _vp
 hostlib.bdpt_host_scene_create.argtypes = [C.c_int, C.c_int, C.c_uint32]
@@ -471,3 +489,68 @@ class Context:
         ms = C.c_float()
         self._check(lib.bdpt_last_launch_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+class Group:
+    """One bdpt_group: several GPUs of this node (one context each, one process), samples dealt to them."""
+
+    def __init__(self, devices, width, height, combine=COMBINE_AUTO):
+        self._h = _vp()
+        self.width, self.height = width, height
+        arr = (C.c_int * len(devices))(*devices)
+        rc = lib.bdpt_group_create(arr, len(devices), width, height, combine, C.byref(self._h))
+        if rc != 0:
+            raise BdptError(rc, lib.bdpt_group_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            lib.bdpt_group_destroy(self._h)
+            self._h = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BdptError(rc, lib.bdpt_group_last_error(self._h).decode())
+
+    @property
+    def size(self):
+        return lib.bdpt_group_size(self._h)
+
+    @property
+    def combine(self):
+        return lib.bdpt_group_combine(self._h)
+
+    @property
+    def num_samples(self):
+        return lib.bdpt_group_num_samples(self._h)
+
+    def set_params(self, params):
+        self._check(lib.bdpt_group_set_params(self._h, C.byref(params)))
+
+    def upload_scene(self, scene):
+        self._check(lib.bdpt_group_upload_scene(self._h, _ptr(scene.spheres), len(scene.spheres), _ptr(scene.planes),
+                                                len(scene.planes), _ptr(scene.triangles), len(scene.triangles),
+                                                _ptr(scene.surfaces), len(scene.surfaces)))
+
+    def upload_seeds(self, seeds):
+        seeds = _as(seeds, np.uint32)
+        if seeds.size != self.width * self.height * 4:
+            raise ValueError("seeds must hold width*height*4 words")
+        self._check(lib.bdpt_group_upload_seeds(self._h, _ptr(seeds)))
+
+    def set_camera(self, camera):
+        cam = _as(camera, camera_dtype)
+        self._check(lib.bdpt_group_set_camera(self._h, cam.ctypes.data_as(_vp)))
+
+    def render(self, spp):
+        self._check(lib.bdpt_group_render(self._h, spp))
+
+    def read_image(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib.bdpt_group_read_image(self._h, _ptr(out)))
+        return out

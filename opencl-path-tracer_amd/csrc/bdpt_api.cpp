@@ -21,6 +21,7 @@
 
 #include "../../include/bdpt.h"
 #include "../../include/bdpt_clmath.h"
+#include "bdpt_ctx_internal.h"
 #include "bdpt_kernels.h"
 #include "bdpt_layout.h"
 
@@ -104,6 +105,9 @@ static hipError_t dev_upload(T *&dst, const std::vector<T> &src)
 }
 
 static clm_f3 v3(const float *p) { return clm_make3(p[0], p[1], p[2]); }
+
+int bdpt_ctx_device(const bdpt_ctx *ctx) { return ctx->device; }
+hipStream_t bdpt_ctx_stream(const bdpt_ctx *ctx) { return ctx->stream; }
 
 extern "C" {
 

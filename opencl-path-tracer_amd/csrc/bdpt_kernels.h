@@ -28,6 +28,10 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
 /* The reference's older unidirectional kernel (kernel0.cl:872-1001): spp samples per pixel of the region in one launch. */
 hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream);
 
+/* dst[i] += src[i] and dst[i] *= factor over n float4 on one device (combining partial sums of several GPUs). */
+hipError_t bdpt_launch_add(float4 *dst, const float4 *src, size_t n, hipStream_t stream);
+hipError_t bdpt_launch_scale(float4 *dst, size_t n, float factor, hipStream_t stream);
+
 /* Closest hit of n caller-supplied rays (6 floats each: origin, direction;
  * origin[2*i], origin[2*i+1] = primitive to skip or (4,0)). Device pointers. */
 hipError_t bdpt_launch_query(const bdpt_dev_scene &S, const float *rays, const int *origin, int n, int *out_id,

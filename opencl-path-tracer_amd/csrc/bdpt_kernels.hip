@@ -1070,6 +1070,23 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_path_trace_kernel(const bdpt_
     }
 }
 
+/* dst += src and dst *= f over n float4: combining the partial sums of several GPUs on one of them */
+__global__ void bdpt_add_kernel(float4 *dst, const float4 *src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+__global__ void bdpt_scale_kernel(float4 *dst, size_t n, float f)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = dst[i];
+    dst[i] = make_float4(a.x * f, a.y * f, a.z * f, a.w * f);
+}
+
 /* Closest hit for caller-supplied rays: the unit the known-answer tests drive. */
 __global__ void bdpt_query_kernel(bdpt_dev_scene S, const float *rays, const int *origin, int n, int *out_id,
                                   float *out_pos, float *out_n)
@@ -1201,6 +1218,20 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
         else BDPT_LAUNCH(false, false, false);
     }
 #undef BDPT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_add(float4 *dst, const float4 *src, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bdpt::bdpt_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_scale(float4 *dst, size_t n, float factor, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bdpt::bdpt_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, n, factor);
     return hipGetLastError();
 }
 

@@ -98,6 +98,10 @@ struct InputFrame {
 class Renderer {
 public:
     Renderer(int device, int width, int height);
+    /* Several GPUs of the node behind one renderer (bdpt_group_*): every frame's samples are dealt to the
+     * devices and the image is the combined mean.  The reference has one device; with a list of one this is
+     * still a group (counter-addressed generator, sum accumulation), not the single-device renderer above. */
+    Renderer(const std::vector<int> &devices, int width, int height, int combine = BDPT_COMBINE_AUTO);
     ~Renderer();
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
@@ -120,13 +124,17 @@ public:
     bool loadCheckpoint(const std::string &path, std::string *err = nullptr);
     float lastLaunchMs();
     bdpt_ctx *ctx() { return c; }
+    bdpt_group *group() { return g; }
+    int numDevices() const;
     int width() const { return w; }
     int height() const { return h; }
     bool verbose = true;                         /* "numSamples: N" every 10 samples (main.cpp:168-169) */
 
 private:
     void check(int rc, const char *what);        /* main.cpp:41-46: print and exit */
-    bdpt_ctx *c = nullptr;
+    void initCamera();
+    bdpt_ctx *c = nullptr;                       /* single device ... */
+    bdpt_group *g = nullptr;                     /* ... or a group of them */
     int w, h;
     ModelCamera cam;
 };

@@ -8,14 +8,17 @@
  *   bdpt_host [--scene cornell|planes|outdoor|soup] [--soup N] [--scene-file F]
  *             [--obj model.obj [--obj-surface I] [--obj-scale S] [--obj-translate X,Y,Z]]
  *             [--width W] [--height H] [--frames F] [--spp S] [--orbit-frames K]
- *             [--seed G] [--device D] [--out image.pfm|.ppm|.png [--gamma G]] [--quiet]
+ *             [--seed G] [--device D | --devices D0,D1,... [--combine auto|rccl|copy]]
+ *             [--out image.pfm|.ppm|.png [--gamma G]] [--quiet]
  *             [--resume state.ckpt] [--checkpoint state.ckpt]
  */
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "bdpt_host.h"
 
@@ -31,6 +34,8 @@ int main(int argc, char **argv)
     int frames = 64, spp = 1, orbit_frames = 0, n_soup = 100000, device = 0;
     uint32_t seed = 0x5EEDu;
     bool quiet = false;
+    std::vector<int> devices;                       /* --devices: several GPUs, each frame's samples dealt to them */
+    int combine = BDPT_COMBINE_AUTO;
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
             if (i + 1 >= argc) { std::fprintf(stderr, "ERROR: %s needs a value\n", flag); std::exit(EXIT_FAILURE); }
@@ -45,6 +50,22 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--orbit-frames")) orbit_frames = std::atoi(next("--orbit-frames"));
         else if (!std::strcmp(argv[i], "--seed")) seed = (uint32_t)std::strtoul(next("--seed"), nullptr, 0);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next("--device"));
+        else if (!std::strcmp(argv[i], "--devices")) {
+            const char *p = next("--devices");
+            while (*p) {
+                char *end = nullptr;
+                devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) { std::fprintf(stderr, "ERROR: --devices needs D0,D1,...\n"); return EXIT_FAILURE; }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+        else if (!std::strcmp(argv[i], "--combine")) {
+            const std::string v = next("--combine");
+            if (v == "auto") combine = BDPT_COMBINE_AUTO;
+            else if (v == "rccl") combine = BDPT_COMBINE_RCCL;
+            else if (v == "copy") combine = BDPT_COMBINE_COPY;
+            else { std::fprintf(stderr, "ERROR: --combine needs auto, rccl or copy\n"); return EXIT_FAILURE; }
+        }
         else if (!std::strcmp(argv[i], "--out")) out_path = next("--out");
         else if (!std::strcmp(argv[i], "--resume")) resume_path = next("--resume");
         else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint_path = next("--checkpoint");
@@ -85,7 +106,12 @@ int main(int argc, char **argv)
         std::printf("%s: %zu vertices, %zu triangles\n", obj_path.c_str(), mesh.positions.size(), n);   /* loader.cpp:83 */
     }
 
-    Renderer r(device, width, height);
+    std::unique_ptr<Renderer> holder(devices.empty() ? new Renderer(device, width, height)
+                                                     : new Renderer(devices, width, height, combine));
+    Renderer &r = *holder;
+    if (!devices.empty())
+        std::printf("%d devices, partial images combined by %s\n", r.numDevices(),
+                    bdpt_group_combine(r.group()) == BDPT_COMBINE_RCCL ? "an RCCL reduce" : "device-to-device copies");
     r.verbose = !quiet;
     r.setScene(scene);
     r.setSeeds(seed);

@@ -9,7 +9,7 @@ OUT=build/ab/$NAME
 mkdir -p "$OUT"
 PKG=opencl-path-tracer_amd
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function "$@" \
-      -shared -x hip $PKG/csrc/bdpt_api.cpp $PKG/csrc/bdpt_kernels.hip -o "$OUT/libbdpt_amd.so"
+      -shared -x hip $PKG/csrc/bdpt_api.cpp $PKG/csrc/bdpt_group.cpp $PKG/csrc/bdpt_kernels.hip -o "$OUT/libbdpt_amd.so" -ldl
 g++ -O2 -std=c++17 -fPIC -Wall -shared $PKG/host/camera.cpp $PKG/host/scenes.cpp $PKG/host/renderer.cpp $PKG/host/scene_io.cpp \
     $PKG/host/image_io.cpp $PKG/host/capi.cpp -o "$OUT/libbdpt_host.so" -L"$OUT" -lbdpt_amd -Wl,-rpath,'$ORIGIN'
 echo "built $OUT"

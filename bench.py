@@ -203,7 +203,7 @@ def main():
         per_rank_ms = gathered
 
     variant = ctx.last_launch_variant()
-    variant_name = {1: "DIRECT", 2: "DUAL", 3: "LDS", 4: "TILED", 5: "LDS2"}.get(variant, str(variant))
+    variant_name = {1: "DIRECT", 3: "LDS", 4: "TILED", 5: "LDS2"}.get(variant, str(variant))
     paths_per_step = world * W * H * SPP
     value = paths_per_step * args.steps / elapsed / 1e6
     out = {

@@ -99,7 +99,7 @@ enum { BDPT_ORDER_AUTO = 0, BDPT_ORDER_INDEX = 1, BDPT_ORDER_ROULETTE_CLASS = 2,
  * REFLECTIVE:   brdf_reflective, kernel0.cl:492-508: one more draw p4 first; p4 > 0.6f samples a
  *               cone of half-angle 3.1415f*0.02f about the mirror image of the direction the subpath
  *               arrived from (the zero vector at the light, as kernel0.cl:659 initialises it), else
- *               the Lambert cone (four draws).  Not available in the DUAL kernel variant.
+ *               the Lambert cone (four draws).
  * LAMBERT_IMP:  brdf_lambertian_imp, kernel0.cl:512-543: one more draw p4 first; p4 > imp_light_weight samples
  *               a cone of half-angle 0.50f*M_PI about the normal, else a cone of half-angle imp_half_angle
  *               about the direction toward the light (the only call the file holds, commented out at :945,
@@ -119,8 +119,6 @@ enum { BDPT_SAMPLER_LAMBERT_CONE = 0, BDPT_SAMPLER_HEMISPHERE = 1, BDPT_SAMPLER_
 enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
 /* Kernel variants; all give identical results.
  * DIRECT: every lane walks the primitive arrays with wave-uniform scalar loads.
- * DUAL:   as DIRECT, but the connection ray and the bounce ray of a light-subpath
- *         vertex walk them together, packed two to a register pair.
  * LDS:    the workgroup keeps the whole scene in LDS (scenes up to 24 KB of records).
  * TILED:  per-triangle bounding spheres are staged through wave-private LDS tiles and the
  *         triangle itself is read only for rays that come near it (any scene size).
@@ -129,7 +127,7 @@ enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
  *         then runs the reference's test only on the one or two triangles it could not rule out.
  * AUTO:   TILED when the scene does not fit LDS2 or when enough of its triangles are small
  *         against the scene for the bounding spheres to pay (estimated at upload), else LDS2. */
-enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, BDPT_KERNEL_DUAL = 2, BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5 };
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, /* 2: a variant that was removed */ BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5 };
 
 typedef struct bdpt_params {
     int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */

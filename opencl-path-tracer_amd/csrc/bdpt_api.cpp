@@ -242,7 +242,7 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown connection_falloff");
     if (p->accum_mode != BDPT_ACCUM_MEAN && p->accum_mode != BDPT_ACCUM_SUM)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
-    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_LDS2)
+    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_LDS2 || p->kernel_variant == 2)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
     if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ADAPTIVE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
@@ -251,8 +251,6 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: sample_order ROULETTE_CLASS / ADAPTIVE needs rng_mode STRIDED and accum_mode SUM");
     if (p->sampler < BDPT_SAMPLER_LAMBERT_CONE || p->sampler > BDPT_SAMPLER_LAMBERT_IMP)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sampler");
-    if (p->sampler != BDPT_SAMPLER_LAMBERT_CONE && p->kernel_variant == BDPT_KERNEL_DUAL)
-        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: the DUAL kernel variant has the LAMBERT_CONE sampler only");
     if (p->integrator != BDPT_INTEGRATOR_BIDIRECTIONAL && p->integrator != BDPT_INTEGRATOR_PATH_TRACE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown integrator");
     if (p->integrator == BDPT_INTEGRATOR_PATH_TRACE && (p->rng_mode != BDPT_RNG_STREAM || p->accum_mode != BDPT_ACCUM_MEAN))
@@ -664,7 +662,6 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         variant = BDPT_KERNEL_DIRECT;
         HIP_TRY(ctx, bdpt_launch_path_trace(K, aov, ctx->stream));
     } else if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
-    else if (variant == BDPT_KERNEL_DUAL) HIP_TRY(ctx, bdpt_launch_dual(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS2) HIP_TRY(ctx, bdpt_launch_lds2(K, aov, ctx->counters_on, ctx->stream));
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));

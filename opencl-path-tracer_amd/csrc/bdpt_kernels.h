@@ -10,9 +10,6 @@
 /* spp samples for every pixel of the region in K; one lane per pixel. */
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
-/* The same work with the connection and bounce rays of a vertex traced together (packed FP32 math). */
-hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
-
 /* The same work with the whole scene resident in LDS (scenes up to BDPT_LDS_SCENE_MAX bytes of records). */
 #define BDPT_LDS_SCENE_MAX (24u * 1024u)
 size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records);

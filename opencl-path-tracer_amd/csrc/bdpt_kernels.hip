@@ -16,7 +16,6 @@
  * numeric contract (include/bdpt_clmath.h) writes out.
  */
 #include "bdpt_device.h"
-#include "bdpt_device2.h"
 #include "bdpt_kernels.h"
 
 /* Workgroup: two wavefronts, i.e. two 8x8 pixel tiles side by side (measured against one and four:
@@ -350,7 +349,7 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     return finish_hit_lds<true>(S, b, d);
 }
 
-enum { MODE_DIRECT = 0, MODE_DUAL = 1, MODE_LDS = 2, MODE_LDS2 = 3 };
+enum { MODE_DIRECT = 0, MODE_LDS = 2, MODE_LDS2 = 3 };
 
 /* per-lane work counters of a counting launch */
 struct Tally {
@@ -465,18 +464,13 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     return false;
 }
 
-template <bool AOV>
-BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
-                          uint32_t &hash, int eye_id[2], float col[4]);   /* defined below */
-
-/* Six wavefronts per SIMD (80 VGPRs, a handful of spills) measure 4.5 % faster than the five the
- * register allocator would settle for at 94 VGPRs; seven and eight spill too much.  The two-ray
- * variant needs its registers. */
+/* Six wavefronts per SIMD (80 VGPRs, a handful of spills outside the closest-hit loops) measure 4 % faster than
+ * the five the register allocator would settle for; seven and eight spill too much. */
 template <bool AOV, bool COUNT, int MODE, bool ALT>
 #ifndef BDPT_LDS2_WAVES
 #define BDPT_LDS2_WAVES 6
 #endif
-__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DUAL ? 4 : MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_DUAL ? 4 : MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
+__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
@@ -507,7 +501,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         uint32_t wp = cur.st_head, dp = 0;
         rng_float(wp, dp);                                                /* :592 */
         const clm_f3 dir = camera_ray(wp, dp, K, xt, yt);
-        const Hit e = trace_one<MODE == MODE_DUAL ? MODE_DIRECT : MODE, false, COUNT>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0, T);
+        const Hit e = trace_one<MODE, false, COUNT>(K.scene, clm_mad3(0.00001f, dir, f3(K.cam_pos)), dir, 4, 0, T);
         const bool early = e.type < 0 || surface_row<MODE>(K.scene, e.surf * 2 + 1).w != 0.0f;   /* :645-656 */
         if (early) cur.cls = -1;
         if (COUNT && !AOV) T.rays++;                 /* a ray this launch form traces on top of the samples' own */
@@ -519,8 +513,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
-        const bool early = MODE == MODE_DUAL ? sample_dual<AOV>(K, xt, yt, w, draws, rays, hash, eye_id, col)
-                                             : sample_direct<AOV, MODE, ALT, AOV, COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col, T);
+        const bool early = sample_direct<AOV, MODE, ALT, AOV, COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col, T);
         if (COUNT) { T.rays += rays - rays_before; if (early) T.early++; else T.full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -570,94 +563,6 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         atomicAdd(&K.counters[3], T.cull);
         atomicAdd(&K.counters[4], T.exact);
     }
-}
-
-/* ------------------------------------------------------------------------- */
-/* Dual-ray variant.  At every light-subpath vertex the reference traces two
- * rays that leave the same primitive: the connection ray toward the eye vertex
- * (kernel0.cl:705) and, if Russian roulette lets the walk go on, the bounce ray
- * (:793).  Neither consumes a random number, so the bounce direction can be
- * drawn first (the draw order :767, :787 is unchanged) and both rays can walk
- * the primitive arrays together, one in each half of a 64-bit register pair:
- * the scene record is read once for both and every add/mul/fma of the two
- * tests issues as one v_pk_* instruction (bdpt_device2.h).                     */
-/* ------------------------------------------------------------------------- */
-
-template <bool AOV>
-BDPT_DEV bool sample_dual(const bdpt_kargs &K, float xt, float yt, uint32_t &w, uint32_t &draws, uint32_t &rays,
-                          uint32_t &hash, int eye_id[2], float col[4])
-{
-    const bdpt_dev_scene &S = K.scene;
-    rng_float(w, draws);                                                  /* :592, discarded */
-    clm_f3 dir = camera_ray(w, draws, K, xt, yt);
-    clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
-    Hit eye = closest_hit_direct(S, eye_pos, dir, 4, 0);                  /* :634 */
-    rays++;
-    if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
-
-    if (eye.type < 0) {                                                   /* :652-656 */
-        col[0] = col[1] = col[2] = col[3] = 0.0f;
-        return true;
-    }
-    const float4 eye_diffuse = S.surf[eye.surf * 2];
-    const float4 eye_emissive = S.surf[eye.surf * 2 + 1];
-    if (eye_emissive.w != 0.0f) {                                         /* :645-650 */
-        col[0] = eye_diffuse.x; col[1] = eye_diffuse.y; col[2] = eye_diffuse.z; col[3] = eye_diffuse.w;
-        return true;
-    }
-
-    clm_f3 vpos, vn;
-    sample_light(w, draws, K, vpos, vn);                                  /* :669 */
-    int vtype = K.light_origin_type, vidx = K.light_origin_index;
-
-    float full[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             /* :689 */
-    float acc[4] = {1.0f, 1.0f, 1.0f, 1.0f};                              /* :692 */
-    float pre = K.pre_factor0;                                            /* :694 */
-    int taken = 0;
-    for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
-        const clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));      /* :699 */
-        const clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                 /* :761 */
-        const clm_f3 ldir = sample_cone(w, draws, vn, 3.1415f * 0.50f);   /* :767, :486 */
-        const float fate = rng_float(w, draws);                           /* :787 */
-        const bool go_on = !(fate > K.p_con);                             /* :788 */
-
-        i2 ot, oi;
-        ot.x = ot.y = vtype;
-        oi.x = oi.y = vidx;
-        const Hit2 h2 = closest_hit2(S, mk2(true, go_on), pack3(vpos, lpos), pack3(tdir, ldir), ot, oi);   /* :705 and :793 */
-        Hit vis;
-        vis.type = h2.type.x; vis.idx = h2.idx.x; vis.pos = comp3(h2.pos, 0); vis.n = comp3(h2.n, 0); vis.surf = h2.surf.x;
-        rays++;
-        if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
-        float contrib[4];
-        connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
-        pre *= K.p_con;                                                   /* :745 */
-        if (!K.indirect_only || lti != 0) {                               /* :752-755 */
-#pragma unroll
-            for (int k = 0; k < 4; k++) full[k] += contrib[k];
-        }
-        taken++;                                                          /* :757 */
-        if (!go_on) break;                                                /* :788 */
-
-        rays++;
-        if (AOV) hash = hash_step(hash, hit_id(h2.type.y, h2.idx.y));
-        if (h2.type.y < 0) break;                                         /* :812 */
-        const float4 nd = S.surf[h2.surf.y * 2];
-        const float4 ne = S.surf[h2.surf.y * 2 + 1];
-        if (ne.w != 0.0f) break;                                          /* :797-803 */
-        acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
-        vpos = comp3(h2.pos, 1); vn = comp3(h2.n, 1); vtype = h2.type.y; vidx = h2.idx.y;   /* :832 */
-    }
-
-    const float inv_taken = clm_div(1.0f, (float)taken);                  /* :846 */
-    const float ed[4] = {eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float c = K.light_emissive[k] * full[k] * inv_taken;
-        if (!K.indirect_only) c = c * ed[k];                              /* :844 / :846 */
-        col[k] = c;
-    }
-    return false;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1153,14 +1058,12 @@ static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hi
         if (MODE == bdpt::MODE_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return hipErrorInvalidValue;
     }
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
-    if (alt && MODE == bdpt::MODE_DUAL) return hipErrorInvalidValue;
 #define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<A, C, MODE, X>), grid, block, lds, stream, K)
     if (alt) {
-        constexpr bool X = MODE != bdpt::MODE_DUAL;      /* the DUAL kernel has no such instantiation */
-        if (aov && count) BDPT_LAUNCH(true, true, X);
-        else if (aov) BDPT_LAUNCH(true, false, X);
-        else if (count) BDPT_LAUNCH(false, true, X);
-        else BDPT_LAUNCH(false, false, X);
+        if (aov && count) BDPT_LAUNCH(true, true, true);
+        else if (aov) BDPT_LAUNCH(true, false, true);
+        else if (count) BDPT_LAUNCH(false, true, true);
+        else BDPT_LAUNCH(false, false, true);
     } else {
         if (aov && count) BDPT_LAUNCH(true, true, false);
         else if (aov) BDPT_LAUNCH(true, false, false);
@@ -1182,11 +1085,6 @@ size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records)
 hipError_t bdpt_launch_direct(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     return launch_per_pixel<bdpt::MODE_DIRECT>(K, aov, count, stream);
-}
-
-hipError_t bdpt_launch_dual(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
-{
-    return launch_per_pixel<bdpt::MODE_DUAL>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)

@@ -7,7 +7,7 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("case", gu.RENDER_CASES)
 def test_render_matches_golden(bdpt, case, variant):
     g = gu.load(case)
@@ -47,7 +47,7 @@ def test_closest_hit_matches_golden(bdpt):
 
 def _region_variants(case):
     # the 100 000-triangle scene does not fit the LDS-resident kernel; AUTO must resolve to TILED there
-    return [0, 1, 4] if "soup100k" in case else [0, 1, 2, 3, 4, 5]
+    return [0, 1, 4] if "soup100k" in case else [0, 1, 3, 4, 5]
 
 
 @pytest.mark.parametrize("case,variant", [(c, v) for c in gu.REGION_CASES for v in _region_variants(c)])

@@ -248,17 +248,10 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
     const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
     const LdsLayout L = lds_layout<true>(S);
-#ifdef BDPT_DBG_TWICE_SPHERES
-    for (int rep = 0; rep < 2; rep++) {
-    asm volatile("" : "+v"(o.x), "+v"(d.x));
-#endif
     for (int i = 0; i < S.n_spheres; i++) {
         const float4 s = bdpt_lds[L.sph + i];
         if (i != skip_s) test_sphere(b, s, i, o, d);
     }
-#ifdef BDPT_DBG_TWICE_SPHERES
-    }
-#endif
     for (int i = 0; i < S.n_planes; i++) {
         const float4 q0 = bdpt_lds[L.pln + i * BDPT_PLN_F4], q1 = bdpt_lds[L.pln + i * BDPT_PLN_F4 + 1];
         if (i != skip_p) test_plane(b, q0, q1, i, o, d);
@@ -269,10 +262,6 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     for (int base = 0; base < S.n_triangles; base += 32) {
         const int cnt = min(32, S.n_triangles - base);
         uint32_t mask = 0u;
-#ifdef BDPT_DBG_TWICE_STAGE1      /* timing experiment: the same masks computed twice */
-        for (int rep = 0; rep < 2; rep++) {
-        asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(mask));
-#endif
         const uint32_t same = S.cull_same[base >> 5];
         /* the plane part of a triangle's test: val (exact, :286), -1/val... and the approximate point on the plane */
         struct PlaneHit { float val, r, px, py, pz; };
@@ -320,17 +309,8 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             const PlaneHit h = plane_part(c[0]);
             mask |= kept(h, c[1], c[2], cull_s[base + j]) ? (1u << j) : 0u;
         }
-#ifdef BDPT_DBG_TWICE_STAGE1
-        }
-#endif
         if (COUNT) *n_cull += (unsigned long long)cnt;
         if (skip_t >= base && skip_t < base + 32) mask &= ~(1u << (skip_t - base));                   /* :436 */
-#ifdef BDPT_DBG_TWICE_STAGE2      /* timing experiment: every candidate tested twice (the second time changes nothing) */
-        const uint32_t mask_again = mask;
-        for (int rep = 0; rep < 2; rep++) {
-        asm volatile("" : "+v"(o.x), "+v"(d.x));
-        mask = mask_again;
-#endif
         while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0) {            /* stage 2 */
             const bool wanted = mask != 0u;
             const int i = base + (wanted ? __builtin_ctz(mask) : 0);      /* a lane with nothing left reads a record it ignores */
@@ -342,9 +322,6 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             test_triangle_flat(b, q0, q1, q2, q3, q4, e2z, i, wanted, o, d);
             if (COUNT && wanted) ++*n_exact;
         }
-#ifdef BDPT_DBG_TWICE_STAGE2
-        }
-#endif
     }
     return finish_hit_lds<true>(S, b, d);
 }

@@ -323,7 +323,7 @@ def main():
         cpu_s = time.perf_counter() - t0
         n_paths = gx * gy * bw * bh * cspp
         out["cpu_baseline"] = {
-            "value": round(n_paths / cpu_s / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "value": round(n_paths / cpu_s / 1e6, 6), "unit": "Mpaths/s", "cores": threads, "kind": "port",
             "sample": "%d x %d blocks of %dx%d pixels spread evenly over the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s"
                       % (gx, gy, bw, bh, W, H, cspp, cpu_s),
             "reference_opencl_on_cpu": cpu_opencl_status(),

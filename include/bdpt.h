@@ -126,7 +126,8 @@ enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
  *         triangle first gets a cheap conservative test from all lanes together, and each lane
  *         then runs the reference's test only on the one or two triangles it could not rule out.
  * AUTO:   TILED when the scene does not fit LDS2 or when enough of its triangles are small
- *         against the scene for the bounding spheres to pay (estimated at upload), else LDS2. */
+ *         against the scene for the bounding spheres to pay (estimated at upload), else LDS2
+ *         (LDS for a scene without triangles). */
 enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, /* 2: a variant that was removed */ BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5 };
 
 typedef struct bdpt_params {

@@ -305,6 +305,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     std::vector<float> cull_s(n_triangles);
+    std::vector<double> big_r2(n_triangles);           /* 1.05 R^2 of each bounding sphere, for AUTO's estimate */
     double cull_c = 0.0;
     std::memset(ctx->cull_same, 0, sizeof ctx->cull_same);
     for (int i = 0; i < n_spheres; i++) {
@@ -351,7 +352,15 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         double longest2 = 0.0;
         for (const auto &e : ex) longest2 = std::max(longest2, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
         const bool well_shaped = std::sqrt(crx * crx + cry * cry + crz * crz) >= 1.0e-3 * longest2;
-        bound[i] = make_float4(cx, cy, cz, well_shaped ? std::nextafter((float)(r2 * 1.05), INFINITY) : INFINITY);
+        /* stored: w = (1 - 1e-5) |c|^2 - 1.05 R^2 - 2e-6 |c|^2, rounded down (the device test and the last term: bdpt_kernels.hip);
+         * -inf = never out of reach, for slivers and for numbers so large that the device's float arithmetic could overflow */
+        {
+            const double cc = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+            const double wd = 0.99999 * cc - r2 * 1.05 - 2.0e-6 * cc;
+            const bool tame = well_shaped && cc < 1.0e30 && r2 < 1.0e30;
+            bound[i] = make_float4(cx, cy, cz, tame ? std::nextafter((float)wd, -INFINITY) : -INFINITY);
+            big_r2[i] = well_shaped ? r2 * 1.05 : INFINITY;
+        }
         tri_s[i] = t.surface;
         /* Records of the two-stage kernel's conservative test (closest_hit_lds2, where the margin is derived).
          * In exact arithmetic the reference's edge expressions (kernel0.cl:298-300) are, for a point p of the
@@ -431,7 +440,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         const double big2 = diag2 / 4.0 / 64.0 * 1.05;                     /* (extent / 8)^2, against the stored 1.05 R^2 */
         long long n_big = 0;
         for (int i = 0; i < n_triangles; i++)
-            if (!(bound[i].w < big2)) n_big++;
+            if (!(big_r2[i] < big2)) n_big++;
         ctx->auto_tiled = n_triangles > 0 && 13LL * n_triangles + 110LL * n_big < 64LL * n_triangles;
     }
     ctx->spheres.assign(spheres, spheres + n_spheres);
@@ -655,7 +664,8 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
     /* AUTO: see the estimate in bdpt_upload_scene */
     if (variant == BDPT_KERNEL_AUTO)
-        variant = (bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_TILED;
+        variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_TILED
+                  : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (ctx->params.integrator == BDPT_INTEGRATOR_PATH_TRACE) {

@@ -18,7 +18,7 @@
  *       q4 (b.y,  b.z,  e2.x, e2.y)   e2 = a-b
  *       q5 (e2.z, ns.x, ns.y, ns.z)   ns = normalize(cross(a-b, b-c)), the
  *                                     shading normal of kernel0.cl:467
- *   triangle bound 1 x float4 : (centre.xyz, 1.05 * radius^2) of a sphere around the three
+ *   triangle bound 1 x float4 : (centre c, (1 - 1e-5 - 2e-6) |c|^2 - 1.05 radius^2) of a sphere around the three
  *       vertices: what the tiled kernel streams; a ray that passes the sphere by more than
  *       rounding can explain cannot hit the triangle, and only the others read the record
  *   triangle cull 3 x float4 + 1 float : what the two-stage LDS kernel's conservative test reads, computed

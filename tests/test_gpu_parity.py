@@ -415,7 +415,8 @@ def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
             ctx.render(1)
             return ctx.last_launch_variant()
     assert variant_for(bdpt.Scene.cornell()) == bdpt.KERNEL_LDS2
-    assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS2
+    assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS     # no triangles: nothing for two stages to do
+    assert variant_for(bdpt.Scene.outdoor()) == bdpt.KERNEL_LDS
     assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS2
     assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_TILED
     assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_TILED

@@ -50,6 +50,10 @@ KERNEL(k_cmp,    "v_cmp_gt_f32 vcc, %8, %0\n v_cmp_gt_f32 vcc, %8, %1\n v_cmp_gt
 KERNEL(k_cnd,    "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n")
 KERNEL(k_cnd_s,  "v_cndmask_b32 %0, %0, %1, s[40:41]\n v_cndmask_b32 %2, %2, %3, s[40:41]\n v_cndmask_b32 %4, %4, %5, s[40:41]\n v_cndmask_b32 %6, %6, %7, s[40:41]\n")
 KERNEL(k_cnd_ind,"v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n v_cndmask_b32 %6, %7, %1, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n")
+KERNEL(k_cmpcnd_v, "v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_gt_f32 vcc, %4, %5\n v_cndmask_b32 %6, %6, %7, vcc\n")
+KERNEL(k_cmpcnd_s, "v_cmp_gt_f32 s[40:41], %0, %1\n v_cndmask_b32 %2, %2, %3, s[40:41]\n v_cmp_gt_f32 s[40:41], %4, %5\n v_cndmask_b32 %6, %6, %7, s[40:41]\n")
+KERNEL(k_cmpaddc,  "v_cmp_gt_f32 vcc, %0, %1\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_cmp_gt_f32 vcc, %4, %5\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n")
+KERNEL(k_min3,     "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %3, %3, %4, %5\n v_min3_f32 %6, %6, %7, %1\n v_min3_f32 %2, %2, %4, %5\n")
 KERNEL(k_cmp_e64,"v_cmp_gt_f32 s[40:41], %0, %1\n v_cmp_gt_f32 s[40:41], %2, %3\n v_cmp_gt_f32 s[40:41], %4, %5\n v_cmp_gt_f32 s[40:41], %6, %7\n")
 KERNEL(k_cmp_vv, "v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %4, %5\n v_cmp_gt_f32 vcc, %6, %7\n")
 KERNEL(k_movs,   "v_mov_b32 %0, %8\n v_mov_b32 %2, %8\n v_mov_b32 %4, %8\n v_mov_b32 %6, %8\n")
@@ -105,6 +109,10 @@ int main()
     run("cndmask", k_cnd, out, cyc, cus, w);
     run("cndmask sgpr", k_cnd_s, out, cyc, cus, w);
     run("cndmask indep", k_cnd_ind, out, cyc, cus, w);
+    run("cmp+cndmask via vcc (per instr)", k_cmpcnd_v, out, cyc, cus, w);
+    run("cmp+cndmask via sgpr pair (per instr)", k_cmpcnd_s, out, cyc, cus, w);
+    run("cmp+addc via vcc (per instr)", k_cmpaddc, out, cyc, cus, w);
+    run("min3", k_min3, out, cyc, cus, w);
     run("cmp e64 sgpr", k_cmp_e64, out, cyc, cus, w);
     run("cmp vcc v,v", k_cmp_vv, out, cyc, cus, w);
     run("mov from sgpr", k_movs, out, cyc, cus, w);

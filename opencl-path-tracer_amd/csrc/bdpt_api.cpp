@@ -625,6 +625,18 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.max_l = P.max_light_bounces;
     K.p_con = P.p_continue;
     K.pre_factor0 = clm_div(1.0f - P.p_continue, 1.0f - clm_powi(P.p_continue, P.max_light_bounces));   /* kernel0.cl:694 */
+    {
+        float pre = K.pre_factor0;
+        for (int k = 0; k < BDPT_INV_PRE_N; k++) { K.inv_pre[k] = clm_div(1.0f, pre); pre *= P.p_continue; }   /* kernel0.cl:741, :745 */
+        /* sqrt is monotone and correctly rounded, so "sqrt(x) < 0.0001f" holds exactly below one threshold */
+        uint32_t lo = 0u, hi = 0x7F800000u;                               /* smallest bit pattern whose root is >= 0.0001f */
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            float x; std::memcpy(&x, &mid, 4);
+            if (clm_sqrt(x) >= 0.0001f) hi = mid; else lo = mid + 1u;
+        }
+        std::memcpy(&K.same_point_d2, &lo, 4);
+    }
     K.indirect_only = P.indirect_only;
     K.rng_mode = P.rng_mode;
     K.falloff = P.connection_falloff;

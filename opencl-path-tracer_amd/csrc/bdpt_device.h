@@ -366,17 +366,25 @@ BDPT_DEV uint32_t hit_id(int type, int idx)
     return type < 0 ? 0xFFFFFFFFu : (((uint32_t)type << 28) | (uint32_t)idx);
 }
 
+/* 1 / preFactor of light-subpath vertex lti (kernel0.cl:694, :745): the first entries come from the host's table */
+BDPT_DEV float inv_pre_factor(const bdpt_kargs &K, int lti, float pre)
+{
+    return lti < BDPT_INV_PRE_N ? K.inv_pre[lti] : clm_div(1.0f, pre);
+}
+
 /*
  * kernel0.cl:712-744: contribution of one light-subpath vertex to the eye
  * vertex, all four channels.  `vis` is the closest hit of the ray from the
- * light vertex toward the eye vertex.
+ * light vertex toward the eye vertex; inv_imp is 1 / preFactor (:741), see
+ * inv_pre_factor().
  */
 BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, clm_f3 vert_pos, clm_f3 vert_n,
-                         clm_f3 test_dir, const float acc[4], float pre_factor, float out[4])
+                         clm_f3 test_dir, const float acc[4], float inv_imp, float out[4])
 {
     out[0] = out[1] = out[2] = out[3] = 0.0f;
     if (eye.type != vis.type || eye.idx != vis.idx) return;                          /* :712 */
-    if (!(clm_length3(clm_sub3(eye.pos, vis.pos)) < 0.0001f)) return;                /* :714 */
+    const clm_f3 gap = clm_sub3(eye.pos, vis.pos);
+    if (!(clm_dot3(gap, gap) < K.same_point_d2)) return;                             /* :714, length < 0.0001f without the root */
     if (!(clm_dot3(eye.n, vis.n) > 0)) return;
     clm_f3 pv = clm_sub3(vis.pos, vert_pos);                                         /* :716 */
     float r2 = pv.x * pv.x + pv.y * pv.y + pv.z * pv.z;
@@ -384,7 +392,6 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
                                                          : clm_div(1.0f, r2);        /* :719 */
     float df = clm_dot3(eye.n, test_dir) * clm_dot3(vert_n, test_dir);               /* :732 */
     df *= clm_sign(df);                                                              /* :733 */
-    float inv_imp = clm_div(1.0f, pre_factor);
 #pragma unroll
     for (int k = 0; k < 4; k++) out[k] = acc[k] * sf * df * inv_imp;                 /* :741 */
 }

@@ -395,7 +395,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
             float contrib[4];
-            connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+            connection(K, eye, vis, vpos, vn, tdir, acc, inv_pre_factor(K, lti, pre), contrib);
             if (!K.indirect_only || lti != 0) {                           /* :752-755 */
 #pragma unroll
                 for (int k = 0; k < 4; k++) full[k] += contrib[k];
@@ -721,7 +721,7 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
             float contrib[4];
-            connection(K, eye, vis, vpos, vn, tdir, acc, pre, contrib);
+            connection(K, eye, vis, vpos, vn, tdir, acc, inv_pre_factor(K, lti, pre), contrib);
             if (!K.indirect_only || lti != 0) {                           /* :752-755 */
 #pragma unroll
                 for (int k = 0; k < 4; k++) full[k] += contrib[k];

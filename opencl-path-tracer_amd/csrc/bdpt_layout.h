@@ -63,6 +63,8 @@ struct bdpt_dev_scene {
     int n_spheres, n_planes, n_triangles, n_surfaces;
 };
 
+#define BDPT_INV_PRE_N 8
+
 struct bdpt_kargs {
     bdpt_dev_scene scene;
     /* per-pixel state, row-major y*width + x */
@@ -95,6 +97,8 @@ struct bdpt_kargs {
     int max_l;
     float p_con;
     float pre_factor0;
+    float inv_pre[BDPT_INV_PRE_N];   /* 1 / preFactor at light-subpath vertex k: preFactor starts at pre_factor0 and is multiplied by p_con per vertex (:745) */
+    float same_point_d2;        /* smallest float whose square root is >= 0.0001f: length(v) < 0.0001f (:714) iff dot(v,v) < same_point_d2 */
     int indirect_only;
     int rng_mode;
     int falloff;

@@ -25,20 +25,164 @@
 
 namespace bdpt {
 
-/* Pixel of this lane.  Whole region: a 2-D grid of workgroups, 16x8 pixels each.  Interleaved tile split: a 1-D
- * grid that enumerates, tile after tile, the workgroups of the tiles this launch owns. */
-BDPT_DEV void lane_pixel(const bdpt_kargs &K, int &x, int &y)
+/*
+ * A launch in slices.
+ *
+ * A lane keeps its pixel for the whole launch, so a workgroup's run time grows with the sample
+ * count, and a launch ends with the machine draining: the last workgroups run on a chip that is
+ * mostly idle, for about as long as one workgroup takes (13.6 of 90 ms for 512 samples of the
+ * Cornell box at 1080p).  A sliced launch cuts the samples of every workgroup's tile into
+ * n_chunks runs of chunk_spp samples and starts n_chunks times as many workgroups, each of which
+ * takes one run of one tile: the drain shrinks with the run.
+ *
+ * Which run of which tile a workgroup takes is decided by a ticket drawn from a counter when it
+ * starts (ticket t: run t / n_tiles of tile t % n_tiles), not by its number in the grid, so the
+ * run before it on the same tile belongs to a workgroup that drew its ticket earlier and is
+ * therefore running or done, whatever order the hardware starts workgroups in.  It waits for that
+ * workgroup's "tile done up to run r" word before it reads the pixel state the run left in memory
+ * (accumulator, generator word, sample cursor, parity buffers), and publishes its own when it has
+ * written them.  A run is to the samples exactly what a launch of its own would be, except that
+ * the sample cursor carries over, so the order of the samples of a launch -- and with it every
+ * bit of the result -- is that of the unsliced launch.
+ */
+struct Slice {
+    int tile;               /* workgroup-sized tile of the launch's grid, row by row */
+    int run;
+    int s0, s1;             /* the samples s0 <= s < s1 of the launch's order, for every pixel of the tile */
+    bool shared;            /* the launch is sliced: pixel state written here is read by another workgroup of this launch */
+};
+
+typedef __attribute__((address_space(1))) uint32_t slice_u32;
+typedef __attribute__((address_space(1))) unsigned long long slice_u64;
+#define BDPT_SLICE_HEADER 4                 /* words in front of the per-tile words: ticket counter, give-up mark, padding */
+#define BDPT_SLICE_SPIN_LIMIT (1u << 24)    /* polls (about a microsecond apart) before a workgroup gives up on the run before it */
+
+BDPT_DEV Slice slice_begin(const bdpt_kargs &K)
+{
+    Slice sl;
+    sl.shared = K.n_chunks > 1;
+    if (!sl.shared) {
+        sl.tile = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        sl.run = 0;
+        sl.s0 = 0;
+        sl.s1 = K.spp;
+        return sl;
+    }
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) {
+        slice_u32 *sync = (slice_u32 *)(uintptr_t)K.slice_sync;
+        const uint32_t t = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t run = t / (uint32_t)K.n_tiles, tile = t % (uint32_t)K.n_tiles;
+        /* The holder of ticket t - n_tiles is resident (it has drawn its ticket) and waits only for lower tickets, so
+         * this ends; the limit is a guard against a fault elsewhere, and the host reports a launch that hit it. */
+        uint32_t polls = 0;
+        while (__hip_atomic_load(sync + BDPT_SLICE_HEADER + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < run) {
+            if (++polls > BDPT_SLICE_SPIN_LIMIT) {
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        /* one invalidate of this compute unit's vector cache, after the word matched; the wait holds the barrier
+         * below until it has completed, and then every wave of the workgroup may load the state */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = t;
+    }
+    __syncthreads();
+    const uint32_t t = ticket;
+    sl.tile = (int)(t % (uint32_t)K.n_tiles);
+    sl.run = (int)(t / (uint32_t)K.n_tiles);
+    sl.s0 = sl.run * K.chunk_spp;
+    sl.s1 = min(K.spp, sl.s0 + K.chunk_spp);
+    return sl;
+}
+
+/* Every thread of the workgroup, after its last store of pixel state.  The state of a sliced launch is stored
+ * write-through (state_store below), so it needs no write-back of the second-level cache: every wave waits for its
+ * own stores, the workgroup meets, one lane raises the tile's word. */
+BDPT_DEV void slice_end(const bdpt_kargs &K, const Slice &sl)
+{
+    if (!sl.shared) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store((slice_u32 *)(uintptr_t)K.slice_sync + BDPT_SLICE_HEADER + sl.tile, (uint32_t)sl.run + 1u,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* Stores of pixel state (accumulator, generator word, cursor, parity buffers).  shared: another workgroup of
+ * this launch reads the bytes, on whichever of the eight dies it runs: write through the caches. */
+BDPT_DEV void state_store(bool shared, uint32_t *p, uint32_t v)
+{
+    if (shared) __hip_atomic_store((slice_u32 *)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+BDPT_DEV void state_store(bool shared, uint2 *p, uint2 v)
+{
+    if (shared) __hip_atomic_store((slice_u64 *)(uintptr_t)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+BDPT_DEV void state_store(bool shared, uint4 *p, uint4 v)
+{
+    if (shared) {
+        state_store(true, (uint2 *)p, make_uint2(v.x, v.y));
+        state_store(true, (uint2 *)p + 1, make_uint2(v.z, v.w));
+    } else *p = v;
+}
+BDPT_DEV void state_store(bool shared, float4 *p, float4 v)
+{
+    state_store(shared, (uint4 *)p, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+
+/* the sample cursor of a pixel between two runs of a sliced launch */
+BDPT_DEV void cursor_load(SampleCursor &c, const bdpt_kargs &K, size_t pix)
+{
+    const uint4 v = K.slice_cursor[pix];
+    c.cls = (int)v.x; c.head = (int)v.y; c.st_head = v.z; c.pending = v.w;
+}
+BDPT_DEV void cursor_store(const SampleCursor &c, const bdpt_kargs &K, size_t pix)
+{
+    state_store(true, &K.slice_cursor[pix], make_uint4((uint32_t)c.cls, (uint32_t)c.head, c.st_head, c.pending));
+}
+
+/* what a run leaves in memory for the next run or the next launch */
+template <bool AOV>
+BDPT_DEV void pixel_state_store(const bdpt_kargs &K, const Slice &sl, size_t pix, const float acc[4], uint32_t w, const SampleCursor &cur,
+                                const int eye_id[2], uint32_t hash, const float col[4], uint32_t draws, uint32_t rays)
+{
+    state_store(sl.shared, &K.accum[pix], make_float4(acc[0], acc[1], acc[2], acc[3]));   /* kernel0.cl:863 */
+    if (K.rng_mode == BDPT_RNG_STREAM) state_store(sl.shared, &K.seed_w[pix], w);        /* :861 */
+    if (sl.s1 < K.spp) cursor_store(cur, K, pix);
+    if (AOV) {
+        state_store(sl.shared, (uint2 *)&K.aov_eye_hit[pix * 2], make_uint2((uint32_t)eye_id[0], (uint32_t)eye_id[1]));
+        state_store(sl.shared, &K.aov_hit_hash[pix], hash);
+        state_store(sl.shared, &K.aov_radiance[pix], make_float4(col[0], col[1], col[2], col[3]));
+        state_store(sl.shared, &K.aov_rng_draws[pix], draws);
+        state_store(sl.shared, &K.aov_rays[pix], rays);
+    }
+}
+
+/* Pixel of this lane in tile `tile`.  Whole region: the tiles are 16x8 pixels, wg_x per row.  Interleaved tile
+ * split: the tiles enumerate, split tile after split tile, the workgroups of the split tiles this launch owns. */
+BDPT_DEV void lane_pixel(const bdpt_kargs &K, int tile, int &x, int &y)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int bx = (int)blockIdx.x, by = (int)blockIdx.y, ox = K.rx0, oy = K.ry0;
+    int bx, by, ox = K.rx0, oy = K.ry0;
     if (K.tile_stride > 1) {
         const int bw = K.tile_w / BDPT_BLOCK_W, per_tile = bw * (K.tile_h / 8);
-        const int owned = (int)blockIdx.x / per_tile, local = (int)blockIdx.x % per_tile;
+        const int owned = tile / per_tile, local = tile % per_tile;
         const int t = K.tile_phase + owned * K.tile_stride;
         ox += (t % K.tiles_x) * K.tile_w;
         oy += (t / K.tiles_x) * K.tile_h;
         bx = local % bw;
         by = local / bw;
+    } else if (K.n_chunks <= 1) {
+        bx = (int)blockIdx.x;
+        by = (int)blockIdx.y;
+    } else {
+        bx = tile % K.wg_x;
+        by = tile / K.wg_x;
     }
     x = ox + bx * BDPT_BLOCK_W + wv * 8 + (lane & 7);
     y = oy + by * 8 + (lane >> 3);
@@ -441,6 +585,10 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     return false;
 }
 
+/* all samples of one run of one pixel (the whole launch when it is not sliced) */
+template <bool AOV, bool COUNT, int MODE, bool ALT>
+BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y);
+
 /* Six wavefronts per SIMD (80 VGPRs, a handful of spills outside the closest-hit loops) measure 4 % faster than
  * the five the register allocator would settle for; seven and eight spill too much. */
 template <bool AOV, bool COUNT, int MODE, bool ALT>
@@ -452,9 +600,17 @@ void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
     if (MODE == MODE_LDS2) lds_fill_scene<true>(K.scene);
+    const Slice sl = slice_begin(K);
     int x, y;
-    lane_pixel(K, x, y);
-    if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
+    lane_pixel(K, sl.tile, x, y);
+    if (x < K.rx0 + K.rw && y < K.ry0 + K.rh)
+        direct_pixel<AOV, COUNT, MODE, ALT>(K, sl, x, y);
+    slice_end(K, sl);
+}
+
+template <bool AOV, bool COUNT, int MODE, bool ALT>
+BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
+{
     const size_t pix = (size_t)y * K.width + x;
 
     float4 a4 = K.accum[pix];
@@ -462,7 +618,8 @@ void bdpt_direct_kernel(const bdpt_kargs K)
     const uint32_t seed = K.seed_w[pix];
     uint32_t w = seed;
     SampleCursor cur;
-    cursor_init(cur, K, seed);
+    if (sl.s0 == 0) cursor_init(cur, K, seed);
+    else cursor_load(cur, K, pix);
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
@@ -473,7 +630,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
     float xt, yt;
     pixel_coord(K, x, y, xt, yt);
 
-    if (K.reorder == 2) {
+    if (K.reorder == 2 && sl.s0 == 0) {
         /* ADAPTIVE order: does the eye ray of the launch's first sample index reach the light loop? */
         uint32_t wp = cur.st_head, dp = 0;
         rng_float(wp, dp);                                                /* :592 */
@@ -485,7 +642,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
     }
 
     uint32_t start;
-    for (int s = 0; cursor_next(cur, K, &K.seed_w[pix], start); s++) {                    /* s counts the samples taken so far */
+    for (int s = sl.s0; s < sl.s1 && cursor_next(cur, K, &K.seed_w[pix], start); s++) {   /* s counts the samples taken so far */
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
@@ -499,7 +656,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
              * exactly.  Account for the repeats and stop. */
             w = w_before;
             acc[0] = col[0]; acc[1] = col[1]; acc[2] = col[2]; acc[3] = col[3];
-            const int rest = K.spp - 1 - s;
+            const int rest = sl.s1 - 1 - s;
             if (AOV) {
                 const uint32_t id = hit_id(eye_id[0], eye_id[1]);
                 for (int r = 0; r < rest; r++) hash = hash_step(hash, id);
@@ -523,16 +680,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
         }
     }
 
-    K.accum[pix] = make_float4(acc[0], acc[1], acc[2], acc[3]);           /* :863 */
-    if (K.rng_mode == BDPT_RNG_STREAM) K.seed_w[pix] = w;                 /* :861 */
-    if (AOV) {
-        K.aov_eye_hit[pix * 2] = eye_id[0];
-        K.aov_eye_hit[pix * 2 + 1] = eye_id[1];
-        K.aov_hit_hash[pix] = hash;
-        K.aov_radiance[pix] = make_float4(col[0], col[1], col[2], col[3]);
-        K.aov_rng_draws[pix] = draws;
-        K.aov_rays[pix] = rays;
-    }
+    pixel_state_store<AOV>(K, sl, pix, acc, w, cur, eye_id, hash, col, draws, rays);
     if (COUNT) {
         atomicAdd(&K.counters[0], T.rays);
         atomicAdd(&K.counters[1], T.full);
@@ -567,7 +715,8 @@ void bdpt_direct_kernel(const bdpt_kargs K)
  * and a NaN anywhere fails the comparison, i.e. keeps the triangle.  The left-hand side is
  * evaluated expanded, |v|^2 = |c|^2 - 2 c.o + |o|^2 and v.d = c.d - o.d, with everything that depends on
  * the sphere alone folded into one stored number at upload and everything that depends on the ray alone
- * into one bound per query: ten instructions per sphere instead of thirteen.  The expansion cancels, so
+ * into one bound per query: seven fused operations per sphere (c.d - o.d and w - 2(1 - 1e-5) c.o as one
+ * chain of three each, then one more) and one compare per four spheres, instead of thirteen.  The expansion cancels, so
  * it is good to about 1.2e-6 (|c|^2 + |o|^2) only; both sides of the comparison give 2e-6 of their share
  * of that away (bdpt_api.cpp for |c|^2, `bound` below for |o|^2).  (v.d)^2 is the squared
  * length of v along the ray only for |d| = 1: with |d|^2 = 1 - e the left-hand side is too large by
@@ -616,6 +765,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
     const float oo = clm_dot3(o, o), od = clm_dot3(o, d);
     /* a sphere is out of reach when  w - 2 (1 - 1e-5) c.o - (c.d - o.d)^2  exceeds this (w: see bdpt_layout.h) */
     const float bound = fabsf(dd - 1.0f) <= 4.0e-6f ? 1.0e-5f * (oo + 1.0f) + 2.0e-6f * oo - 0.99999f * oo : INFINITY;
+    const clm_f3 o2 = clm_scale3(-2.0f * 0.99999f, o);                      /* the factor of c.o, folded into the ray's side (one more rounding of 6e-8 |c||o|) */
     const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
     const size_t total_f4 = (size_t)S.n_triangles + 1;                     /* the array is padded by one sphere */
     float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */
@@ -625,6 +775,40 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         r1 = S.tri_bound[base + 64 < total_f4 ? base + 64 : 0];
         r2 = S.tri_bound[base + 128 < total_f4 ? base + 128 : 0];
     };
+#ifdef BDPT_TILED_SCALAR
+    if (active) {
+        const int count = S.n_triangles;
+        if (COUNT) *n_cull += (unsigned long long)count;
+        auto excess = [&](float4 s) {
+            const float u = __builtin_fmaf(s.z, d.z, __builtin_fmaf(s.y, d.y, __builtin_fmaf(s.x, d.x, -od)));
+            const float t = __builtin_fmaf(s.z, o2.z, __builtin_fmaf(s.y, o2.y, __builtin_fmaf(s.x, o2.x, s.w)));
+            return __builtin_fmaf(-u, u, t);
+        };
+        auto full = [&](int i, bool wanted) {
+            if (__builtin_amdgcn_ballot_w64(wanted) == 0) return;
+            const size_t r = (size_t)i * BDPT_TRI_F4;
+            const float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2),
+                         q3 = uload(S.tri, r + 3), q4 = uload(S.tri, r + 4);
+            const float e2z = uload(S.tri, r + 5).x;
+            if (wanted) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
+            if (COUNT && wanted) ++*n_exact;
+        };
+        int j = 0;
+        for (; j + 4 <= count; j += 4) {
+            const float4 s0 = uload(S.tri_bound, j), s1 = uload(S.tri_bound, j + 1), s2 = uload(S.tri_bound, j + 2), s3 = uload(S.tri_bound, j + 3);
+            const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3);
+            const float least = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
+            if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
+                full(j, !(e0 > bound));
+                full(j + 1, !(e1 > bound));
+                full(j + 2, !(e2 > bound));
+                full(j + 3, !(e3 > bound));
+            }
+        }
+        for (; j < count; j++) full(j, !(excess(uload(S.tri_bound, j)) > bound));
+    }
+    return finish_hit(S, b, d);
+#endif
     if (n_tiles > 0) fetch(0);
     for (int tile = 0; tile < n_tiles; tile++) {
         float4 *buf = wave_lds + (tile & 1) * BDPT_TILE_F4;
@@ -637,10 +821,10 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             const int first = tile * BDPT_TILE_TRIS;
             const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
             if (COUNT) *n_cull += (unsigned long long)count;
-            auto excess = [&](float4 s) {                                    /* see the margin above */
-                const clm_f3 c = clm_make3(s.x, s.y, s.z);
-                const float u = clm_dot3(c, d) - od;
-                return __builtin_fmaf(-u, u, __builtin_fmaf(-2.0f * 0.99999f, clm_dot3(c, o), s.w));
+            auto excess = [&](float4 s) {                                    /* see the margin above: seven fused operations */
+                const float u = __builtin_fmaf(s.z, d.z, __builtin_fmaf(s.y, d.y, __builtin_fmaf(s.x, d.x, -od)));
+                const float t = __builtin_fmaf(s.z, o2.z, __builtin_fmaf(s.y, o2.y, __builtin_fmaf(s.x, o2.x, s.w)));
+                return __builtin_fmaf(-u, u, t);
             };
             auto full = [&](int i, bool wanted) {                            /* the reference's test, for the lanes that want it */
                 if (__builtin_amdgcn_ballot_w64(wanted) == 0) return;
@@ -653,8 +837,17 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             };
             int j = 0;
             for (; j + 4 <= count; j += 4) {                                 /* four spheres per LDS round trip */
+#if defined(BDPT_DBG_NOLDS)
+                float4 s0 = buf[j & 3], s1 = buf[(j & 3) + 1], s2 = buf[(j & 3) + 2], s3 = buf[(j & 3) + 3];
+                asm volatile("" : "+v"(s0.x), "+v"(s1.x), "+v"(s2.x), "+v"(s3.x));
+#else
                 const float4 s0 = buf[j], s1 = buf[j + 1], s2 = buf[j + 2], s3 = buf[j + 3];
+#endif
+#if defined(BDPT_DBG_NOVALU)
+                const float e0 = s0.x + s0.w + s0.y + s0.z, e1 = s1.x + s1.w + s1.y + s1.z, e2 = s2.x + s2.w + s2.y + s2.z, e3 = s3.x + s3.w + s3.y + s3.z;
+#else
                 const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3);
+#endif
                 /* one compare for the four: no input here is a NaN (upload replaces what could make one by -inf) */
                 const float least = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
                 if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
@@ -773,13 +966,21 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
     return early;
 }
 
+/* Five wavefronts per SIMD (96 VGPRs; the sphere walk needs few, the spills sit in the path logic around it):
+ * 100 000 triangles 600 -> 548 ms per 2-sample launch against the four the allocator settles for, 500 triangles
+ * 88.7 -> 82.8 ms per 64 samples; six: 543 and 86.2. */
+#ifndef BDPT_TILED_WAVES
+#define BDPT_TILED_WAVES 5
+#endif
 template <bool AOV, bool COUNT, bool ALT>
-__global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs K)
+__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(BDPT_TILED_WAVES, BDPT_TILED_WAVES)))
+void bdpt_tiled_kernel(const bdpt_kargs K)
 {
     __shared__ float4 tiles[BDPT_BLOCK / 64][2 * BDPT_TILE_F4];
     float4 *wave_lds = tiles[threadIdx.x >> 6];
+    const Slice sl = slice_begin(K);
     int x, y;
-    lane_pixel(K, x, y);
+    lane_pixel(K, sl.tile, x, y);
     const bool inside = x < K.rx0 + K.rw && y < K.ry0 + K.rh;             /* lanes outside still help copy tiles */
     const size_t pix = inside ? (size_t)y * K.width + x : 0;
 
@@ -788,7 +989,8 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
     const uint32_t seed = inside ? K.seed_w[pix] : 1u;
     uint32_t w = seed;
     SampleCursor cur;
-    cursor_init(cur, K, seed);
+    if (sl.s0 == 0 || !inside) cursor_init(cur, K, seed);
+    else cursor_load(cur, K, pix);
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV && inside) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
@@ -798,7 +1000,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
     float xt = 0.f, yt = 0.f;
     if (inside) pixel_coord(K, x, y, xt, yt);
 
-    if (K.reorder == 2) {                                 /* ADAPTIVE order, as in bdpt_direct_kernel */
+    if (K.reorder == 2 && sl.s0 == 0) {                   /* ADAPTIVE order, as in bdpt_direct_kernel */
         uint32_t wp = cur.st_head, dp = 0;
         clm_f3 dir = clm_make3(0.f, 0.f, 1.f);
         if (inside) {
@@ -812,7 +1014,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
     }
 
     bool live = inside;                                   /* false once the pixel has no more samples in this launch */
-    for (int s = 0;; s++) {                                               /* s counts the samples taken so far */
+    for (int s = sl.s0; s < sl.s1; s++) {                                 /* s counts the samples taken so far */
         uint32_t start = 0;
         if (live) live = cursor_next(cur, K, &K.seed_w[pix], start);
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;
@@ -826,7 +1028,7 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
             w = w_before;
             acc[0] = col[0]; acc[1] = col[1]; acc[2] = col[2]; acc[3] = col[3];
-            const int rest = K.spp - 1 - s;
+            const int rest = sl.s1 - 1 - s;
             if (AOV) {
                 const uint32_t id = hit_id(eye_id[0], eye_id[1]);
                 for (int r = 0; r < rest; r++) hash = hash_step(hash, id);
@@ -850,24 +1052,17 @@ __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_tiled_kernel(const bdpt_kargs
             for (int k = 0; k < 4; k++) acc[k] = clm_fma(col[k], s2, acc[k] * s1);
         }
     }
-    if (!inside) return;
-    K.accum[pix] = make_float4(acc[0], acc[1], acc[2], acc[3]);           /* :863 */
-    if (K.rng_mode == BDPT_RNG_STREAM) K.seed_w[pix] = w;                 /* :861 */
-    if (AOV) {
-        K.aov_eye_hit[pix * 2] = eye_id[0];
-        K.aov_eye_hit[pix * 2 + 1] = eye_id[1];
-        K.aov_hit_hash[pix] = hash;
-        K.aov_radiance[pix] = make_float4(col[0], col[1], col[2], col[3]);
-        K.aov_rng_draws[pix] = draws;
-        K.aov_rays[pix] = rays;
+    if (inside) {
+        pixel_state_store<AOV>(K, sl, pix, acc, w, cur, eye_id, hash, col, draws, rays);
+        if (COUNT) {
+            atomicAdd(&K.counters[0], c_rays);
+            atomicAdd(&K.counters[1], c_full);
+            atomicAdd(&K.counters[2], c_early);
+            atomicAdd(&K.counters[3], c_cull);
+            atomicAdd(&K.counters[4], c_exact);
+        }
     }
-    if (COUNT) {
-        atomicAdd(&K.counters[0], c_rays);
-        atomicAdd(&K.counters[1], c_full);
-        atomicAdd(&K.counters[2], c_early);
-        atomicAdd(&K.counters[3], c_cull);
-        atomicAdd(&K.counters[4], c_exact);
-    }
+    slice_end(K, sl);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -880,7 +1075,7 @@ template <bool AOV>
 __global__ __launch_bounds__(BDPT_BLOCK) void bdpt_path_trace_kernel(const bdpt_kargs K)
 {
     int x, y;
-    lane_pixel(K, x, y);
+    lane_pixel(K, (int)(blockIdx.y * gridDim.x + blockIdx.x), x, y);
     if (x >= K.rx0 + K.rw || y >= K.ry0 + K.rh) return;
     const size_t pix = (size_t)y * K.width + x;
     const bdpt_dev_scene &S = K.scene;
@@ -1031,11 +1226,30 @@ static dim3 pixel_grid(const bdpt_kargs &K)
     return dim3((unsigned)owned * (K.tile_w / BDPT_BLOCK_W) * (K.tile_h / 8), 1);
 }
 
+/* Grid of a launch that may be sliced.  On entry K.n_tiles is the number of tiles K.slice_sync has room for; a
+ * launch with more tiles than that runs unsliced.  Clears the ticket counter and the per-tile words. */
+static hipError_t sliced_grid(bdpt_kargs &K, dim3 &grid, hipStream_t stream)
+{
+    grid = pixel_grid(K);
+    const long long tiles = (long long)grid.x * grid.y, room = K.n_tiles;
+    K.wg_x = (int)grid.x;
+    K.n_tiles = (int)tiles;
+    if (K.n_chunks > 1 && (tiles > room || tiles * K.n_chunks > 0x7fffffffLL || !K.slice_sync || !K.slice_cursor)) K.n_chunks = 1;
+    if (K.n_chunks <= 1 || tiles == 0) { K.n_chunks = 1; K.chunk_spp = K.spp; return hipSuccess; }
+    grid = dim3((unsigned)(tiles * K.n_chunks));
+    /* ticket counter, give-up mark and the tiles' words; the allocation is padded so that whole 16-byte units can be cleared */
+    const size_t bytes = ((size_t)(BDPT_SLICE_HEADER + tiles) * sizeof(uint32_t) + 15) / 16 * 16;
+    return hipMemsetAsync(K.slice_sync, 0, bytes < 256 ? 256 : bytes, stream);
+}
+
 template <int MODE>
-static hipError_t launch_per_pixel(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    dim3 grid;
+    const dim3 block(BDPT_BLOCK);
+    const hipError_t e = sliced_grid(K, grid, stream);
+    if (e != hipSuccess) return e;
     if (grid.x == 0) return hipSuccess;                  /* this share owns no tile of the region */
     size_t lds = 0;
     if (MODE == bdpt::MODE_LDS || MODE == bdpt::MODE_LDS2) {
@@ -1083,10 +1297,14 @@ hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream
     return launch_per_pixel<bdpt::MODE_LDS2>(K, aov, count, stream);
 }
 
-hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+hipError_t bdpt_launch_tiled(const bdpt_kargs &K_in, bool aov, bool count, hipStream_t stream)
 {
+    bdpt_kargs K = K_in;
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    dim3 grid;
+    const dim3 block(BDPT_BLOCK);
+    const hipError_t e = sliced_grid(K, grid, stream);
+    if (e != hipSuccess) return e;
     if (grid.x == 0) return hipSuccess;
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
 #define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, 0, stream, K)
@@ -1124,6 +1342,7 @@ hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t str
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
     const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
     if (grid.x == 0) return hipSuccess;
+    if (K.n_chunks > 1) return hipErrorInvalidValue;    /* this kernel has no sliced form */
     if (aov) hipLaunchKernelGGL(bdpt::bdpt_path_trace_kernel<true>, grid, block, 0, stream, K);
     else hipLaunchKernelGGL(bdpt::bdpt_path_trace_kernel<false>, grid, block, 0, stream, K);
     return hipGetLastError();

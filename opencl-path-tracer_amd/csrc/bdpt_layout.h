@@ -82,6 +82,13 @@ struct bdpt_kargs {
      * (tiles_x per row), and this launch renders the tiles whose number is tile_phase modulo tile_stride.
      * tile_stride <= 1: the whole region.  tile_w is a multiple of the workgroup's 16 pixels, tile_h of 8. */
     int tile_w, tile_h, tiles_x, tile_stride, tile_phase;
+    /* Sliced launch (see slice_begin in bdpt_kernels.hip): n_chunks > 1 starts n_chunks workgroups per tile, each
+     * running chunk_spp samples.  slice_sync[0] is the ticket counter, slice_sync[1 + t] the number of runs of tile
+     * t that are complete; both zero when the launch starts.  slice_cursor keeps a pixel's sample cursor between
+     * runs.  n_tiles = workgroups of the unsliced grid, wg_x of them per row of the region. */
+    uint32_t *slice_sync;
+    uint4 *slice_cursor;
+    int n_chunks, chunk_spp, n_tiles, wg_x;
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;
     uint32_t first_sample;      /* STRIDED: sample_offset + num_samples */

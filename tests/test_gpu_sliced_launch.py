@@ -1,0 +1,125 @@
+"""Sliced launches (bdpt_set_launch_chunks): a render call run as several runs per tile must leave every bit of the
+pixel state -- accumulator, generator words, parity buffers, counters -- as the unsliced launch does, in every
+generator / accumulation / sample-order mode and kernel, and so must equal the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 88, 52                      # ragged against the 16x8 workgroup tiles
+AOVS = ("AOV_EYE_HIT", "AOV_HIT_HASH", "AOV_RADIANCE", "AOV_RNG_DRAWS", "AOV_RAYS")
+
+MODES = {
+    "stream_mean": {},
+    "strided_mean": dict(rng_mode=1),
+    "strided_sum_index": dict(rng_mode=1, accum_mode=1, sample_order=1),
+    "strided_sum_class": dict(rng_mode=1, accum_mode=1, sample_order=2),
+    "strided_sum_adaptive": dict(rng_mode=1, accum_mode=1, sample_order=3),
+}
+
+
+def _render(bdpt, scene, params, chunks, calls, region=None, interleave=None, counters=False, size=None):
+    w, h = size or (W, H)
+    with bdpt.Context(w, h) as ctx:
+        ctx.set_params(params)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
+        ctx.set_camera(scene.camera)
+        ctx.set_launch_chunks(chunks)
+        if region:
+            ctx.set_region(*region)
+        if interleave:
+            ctx.set_tile_interleave(*interleave)
+        if counters:
+            ctx.enable_counters(True)
+        for spp in calls:
+            ctx.render(spp)
+        out = {"accum": ctx.read_accum(), "seeds": ctx.read_seeds()}
+        if params.aov_enable:
+            for k in AOVS:
+                out[k] = ctx.read_aov(getattr(bdpt, k))
+        if counters:
+            out["counters"] = np.array(ctx.read_counters(), np.uint64)
+        return out
+
+
+def _same(a, b, what, work_counters=True):
+    """work_counters=False: compare only the sample counts.  In STREAM mode a pixel whose eye ray ends the sample
+    repeats that sample for the rest of a launch (kernel0.cl:645-656), which the kernels trace once per run."""
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])
+        if k == "counters" and not work_counters:
+            x, y = x[1:3], y[1:3]
+        assert x.tobytes() == y.tobytes(), "%s: %s differs between the sliced and the unsliced launch" % (what, k)
+
+
+def test_mode_constants(bdpt):
+    assert (bdpt.RNG_STRIDED, bdpt.ACCUM_SUM, bdpt.ORDER_INDEX, bdpt.ORDER_ROULETTE_CLASS, bdpt.ORDER_ADAPTIVE) == (1, 1, 1, 2, 3)
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_sliced_launch_is_bit_identical(bdpt, variant, mode):
+    scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()
+    for aov in (1, 0):
+        p = bdpt.default_params(kernel_variant=variant, aov_enable=aov, **MODES[mode])
+        calls = (3, 37, 8)                               # 37 = 5 runs of 8, 8, 8, 8 and 5 samples
+        whole = _render(bdpt, scene, p, 1, calls, counters=not aov)
+        for chunks in (5, 37):
+            _same(_render(bdpt, scene, p, chunks, calls, counters=not aov), whole, "%s, %d runs, aov %d" % (mode, chunks, aov),
+                  work_counters=mode != "stream_mean")
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+def test_sliced_launch_of_a_region_and_of_interleaved_tiles(bdpt, variant):
+    scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()
+    p = bdpt.default_params(kernel_variant=variant, aov_enable=1, **MODES["strided_sum_adaptive"])
+    for kw in (dict(region=(9, 5, 61, 40)), dict(interleave=(32, 16, 3, 1)), dict(region=(16, 8, 64, 40), interleave=(16, 8, 2, 1))):
+        _same(_render(bdpt, scene, p, 4, (21,), **kw), _render(bdpt, scene, p, 1, (21,), **kw), str(kw))
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+def test_sliced_launch_matches_the_oracle(bdpt, oracle, variant):
+    scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()
+    for mode in ("stream_mean", "strided_sum_adaptive"):
+        p = bdpt.default_params(kernel_variant=variant, aov_enable=1, **MODES[mode])
+        got = _render(bdpt, scene, p, 6, (2, 23))
+        st = oracle.State(W, H, bdpt.make_seeds(W, H, 4242))
+        for spp in (2, 23):
+            oracle.render(st, scene, scene.camera, p, spp, n_threads=8)
+        assert np.array_equal(got["seeds"], st.seeds), mode
+        assert np.array_equal(got["AOV_HIT_HASH"], st.hit_hash), mode
+        assert np.array_equal(got["AOV_RNG_DRAWS"], st.rng_draws), mode
+        assert got["accum"].tobytes() == st.accum.tobytes(), mode
+
+
+def test_automatic_slicing_leaves_results_alone_and_short_launches_whole(bdpt):
+    """chunks = 0: launches of at least 64 samples are sliced by the small-scene kernels, every launch of more than one
+    sample by the many-triangle kernel; results as with one run."""
+    for variant, spp in ((5, 70), (4, 9)):
+        scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()
+        p = bdpt.default_params(kernel_variant=variant, aov_enable=0, **MODES["strided_sum_adaptive"])
+        _same(_render(bdpt, scene, p, 0, (spp, 1)), _render(bdpt, scene, p, 1, (spp, 1)), "automatic, variant %d" % variant)
+
+
+@pytest.mark.parametrize("mode", ["stream_mean", "strided_sum_adaptive"])
+def test_runs_of_a_tile_on_different_dies_at_full_occupancy(bdpt, mode):
+    """A frame of 16 065 tiles (an odd number) with many short runs: workgroups are dealt to the eight dies in turn, so
+    consecutive runs of a tile land on different dies, on a chip that is full; every run reads the state the run
+    before wrote.  Parity buffers on, so that all the state arrays take part."""
+    scene = bdpt.Scene.cornell()
+    p = bdpt.default_params(kernel_variant=5, aov_enable=1, **MODES[mode])
+    size = (1896, 1080)
+    whole = _render(bdpt, scene, p, 1, (48,), size=size)
+    for chunks in (48, 7):
+        _same(_render(bdpt, scene, p, chunks, (48,), size=size), whole, "%s, %d runs" % (mode, chunks))
+
+
+def test_launch_chunks_argument_is_checked(bdpt):
+    with bdpt.Context(16, 8) as ctx:
+        with pytest.raises(bdpt.BdptError):
+            ctx.set_launch_chunks(-1)
+        with pytest.raises(bdpt.BdptError):
+            ctx.set_launch_chunks(100000)
+        ctx.set_launch_chunks(0)

@@ -2,7 +2,7 @@
 bench workload (Cornell, 1920x1080 unless overridden) through the C-ABI, no torch.
 
     python3 tools/prof_run.py [--spp 128] [--launches 2] [--scene cornell|soup:N|outdoor|planes]
-                              [--width W --height H] [--mode strided|stream] [--kernel K]
+                              [--width W --height H] [--mode strided|stream] [--kernel K] [--chunks C]
 """
 import argparse
 import os
@@ -20,6 +20,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mode", default="strided")
 ap.add_argument("--kernel", type=int, default=0)
+ap.add_argument("--chunks", type=int, default=0, help="bdpt_set_launch_chunks (0 = automatic, 1 = unsliced)")
 a = ap.parse_args()
 
 if a.scene.startswith("soup:"):
@@ -34,6 +35,7 @@ else:
 ctx.upload_scene(scene)
 ctx.upload_seeds(bdpt.make_seeds(a.width, a.height, 0x5EED))
 ctx.set_camera(scene.camera)
+ctx.set_launch_chunks(a.chunks)
 ctx.render(min(a.spp, 8))
 ms = []
 for _ in range(a.launches):

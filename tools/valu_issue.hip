@@ -70,6 +70,37 @@ KERNEL(k_mulo,   "v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u
 KERNEL64(k_pkfma_s,"v_pk_fma_f32 %0, %0, s[40:41], %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, %2, s[40:41], %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %4, %4, s[40:41], %4 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %6, %6, s[40:41], %6 op_sel_hi:[1,0,1]\n")
 KERNEL64(k_f64fma, "v_fma_f64 %0, %0, %1, %0\n v_fma_f64 %2, %2, %3, %2\n v_fma_f64 %4, %4, %5, %4\n v_fma_f64 %6, %6, %7, %6\n")
 
+// explicit registers: which VGPR banks (register number mod 4) the three sources of an fma come from
+#define KERNEL_X(name, body)                                                                 \
+    __global__ __launch_bounds__(256) void name(float *out, unsigned long long *cyc, int iters, float a) \
+    {                                                                                        \
+        float r = threadIdx.x;                                                               \
+        asm volatile("v_mov_b32 v20, %0\n v_mov_b32 v21, %0\n v_mov_b32 v22, %0\n v_mov_b32 v23, %0\n v_mov_b32 v24, %0\n v_mov_b32 v25, %0\n" \
+                     "v_mov_b32 v26, %0\n v_mov_b32 v27, %0\n v_mov_b32 v28, %0\n v_mov_b32 v29, %0\n v_mov_b32 v30, %0\n v_mov_b32 v31, %0\n" \
+                     "v_mov_b32 v32, %0\n v_mov_b32 v33, %0\n v_mov_b32 v34, %0\n v_mov_b32 v35, %0\n v_mov_b32 v36, %0\n v_mov_b32 v37, %0\n v_mov_b32 v38, %0\n v_mov_b32 v39, %0\n" \
+                     :: "v"(r) : "v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39"); \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                \
+        for (int i = 0; i < iters; i++) {                                                    \
+            asm volatile(REP8(body) ::: "v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39"); \
+        }                                                                                    \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                \
+        asm volatile("v_add_f32 %0, v20, v21\n v_add_f32 %0, %0, v22\n v_add_f32 %0, %0, v23\n" : "=v"(r) :: "v20","v21","v22","v23"); \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                      \
+        if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0; \
+    }
+KERNEL_X(k_x_banks123, "v_fma_f32 v20, v25, v26, v27\n v_fma_f32 v21, v29, v30, v31\n v_fma_f32 v22, v33, v34, v35\n v_fma_f32 v23, v37, v38, v39\n")
+KERNEL_X(k_x_two_same, "v_fma_f32 v20, v25, v29, v27\n v_fma_f32 v21, v30, v34, v31\n v_fma_f32 v22, v33, v37, v35\n v_fma_f32 v23, v26, v38, v39\n")
+KERNEL_X(k_x_all_same, "v_fma_f32 v20, v24, v28, v32\n v_fma_f32 v21, v25, v29, v33\n v_fma_f32 v22, v26, v30, v34\n v_fma_f32 v23, v27, v31, v35\n")
+KERNEL_X(k_x_fmac,     "v_fmac_f32 v20, v25, v26\n v_fmac_f32 v21, v29, v30\n v_fmac_f32 v22, v33, v34\n v_fmac_f32 v23, v37, v38\n")
+KERNEL_X(k_x_fmac_same,"v_fmac_f32 v20, v24, v28\n v_fmac_f32 v21, v25, v29\n v_fmac_f32 v22, v26, v30\n v_fmac_f32 v23, v27, v31\n")
+// four fma with scalar instructions between them: are the scalar ones issued beside the vector ones or instead of them?
+KERNEL_X(k_x_fma_salu, "v_fma_f32 v20, v25, v26, v27\n s_add_u32 s40, s40, 1\n v_fma_f32 v21, v29, v30, v31\n s_add_u32 s41, s41, 1\n v_fma_f32 v22, v33, v34, v35\n s_add_u32 s40, s40, 1\n v_fma_f32 v23, v37, v38, v39\n s_add_u32 s41, s41, 1\n")
+KERNEL_X(k_x_fma_2salu, "v_fma_f32 v20, v25, v26, v27\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n v_fma_f32 v21, v29, v30, v31\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n v_fma_f32 v22, v33, v34, v35\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n v_fma_f32 v23, v37, v38, v39\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n")
+KERNEL_X(k_x_fma_nop, "v_fma_f32 v20, v25, v26, v27\n s_nop 0\n v_fma_f32 v21, v29, v30, v31\n s_nop 0\n v_fma_f32 v22, v33, v34, v35\n s_nop 0\n v_fma_f32 v23, v37, v38, v39\n s_nop 0\n")
+KERNEL_X(k_x_fma_wait, "v_fma_f32 v20, v25, v26, v27\n s_waitcnt lgkmcnt(0)\n v_fma_f32 v21, v29, v30, v31\n s_waitcnt lgkmcnt(0)\n v_fma_f32 v22, v33, v34, v35\n s_waitcnt lgkmcnt(0)\n v_fma_f32 v23, v37, v38, v39\n s_waitcnt lgkmcnt(0)\n")
+KERNEL_X(k_x_fma_br, "v_fma_f32 v20, v25, v26, v27\n v_fma_f32 v21, v29, v30, v31\n s_cbranch_scc1 1f\n1:\n v_fma_f32 v22, v33, v34, v35\n v_fma_f32 v23, v37, v38, v39\n s_cbranch_vccz 2f\n2:\n")
+KERNEL_X(k_x_fma_lds, "v_mov_b32 v24, 0\n v_fma_f32 v21, v29, v30, v31\n v_fma_f32 v22, v33, v34, v35\n v_fma_f32 v23, v37, v38, v39\n v_fma_f32 v20, v25, v26, v27\n v_fma_f32 v21, v29, v30, v31\n v_fma_f32 v22, v33, v34, v35\n ds_read_b128 v[36:39], v24\n s_waitcnt lgkmcnt(0)\n")
+
 template <class Kn>
 void run(const char *name, Kn kern, float *out, unsigned long long *cyc, int cus, int waves_per_simd)
 {
@@ -82,7 +113,7 @@ void run(const char *name, Kn kern, float *out, unsigned long long *cyc, int cus
     (void)hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     double med = (double)h[h.size() / 2];
-    printf("%-12s waves/SIMD=%d: %.2f SIMD cycles per wave-instruction\n", name, waves_per_simd, med / (32.0 * iters * waves_per_simd));
+    printf("%-32s waves/SIMD=%d: %.2f SIMD cycles per wave-instruction\n", name, waves_per_simd, med / (32.0 * iters * waves_per_simd));
 }
 
 int main()
@@ -98,6 +129,21 @@ int main()
         run("fma vgpr", k_fma_v, out, cyc, cus, w);
         run("fma sgpr", k_fma_s, out, cyc, cus, w);
         run("pk_fma", k_pkfma_v, out, cyc, cus, w);
+    }
+    for (int w : {1, 2, 4, 6, 8}) {
+        run("fma 3 src, banks 1 2 3", k_x_banks123, out, cyc, cus, w);
+        run("fma 3 src, two in one bank", k_x_two_same, out, cyc, cus, w);
+        run("fma 3 src, all in one bank", k_x_all_same, out, cyc, cus, w);
+        run("fmac 2 src, distinct banks", k_x_fmac, out, cyc, cus, w);
+        run("fmac 2 src, dst+src one bank", k_x_fmac_same, out, cyc, cus, w);
+    }
+    for (int w : {1, 4, 6, 8}) {   /* figures are per fma: 4 per body (7 in the last) */
+        run("fma (+1 s_add each), per pair", k_x_fma_salu, out, cyc, cus, w);
+        run("fma (+2 s_add each), per triple", k_x_fma_2salu, out, cyc, cus, w);
+        run("fma (+s_nop each), per pair", k_x_fma_nop, out, cyc, cus, w);
+        run("fma (+s_waitcnt each), per pair", k_x_fma_wait, out, cyc, cus, w);
+        run("2 fma + untaken branch, per 3", k_x_fma_br, out, cyc, cus, w);
+        run("7 valu + ds_read_b128 + wait, per 4", k_x_fma_lds, out, cyc, cus, w);
     }
     const int w = 4;
     run("mul vgpr", k_mul_v, out, cyc, cus, w);

@@ -52,9 +52,9 @@ struct bdpt_ctx {
 
     /* device memory */
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_tri = nullptr, *d_tri_bound = nullptr, *d_tri_cull = nullptr, *d_surf = nullptr;
-    float *d_tri_cull_s = nullptr;
     float cull_c = 0.0f;
-    uint32_t cull_same[BDPT_CULL_MAX_TRIANGLES / 32] = {};
+    int cull_f4 = 0;
+    uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32] = {};
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -203,7 +203,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_tri_cull); dev_free(ctx->d_tri_cull_s); dev_free(ctx->d_surf);
+    dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_tri_cull); dev_free(ctx->d_surf);
     dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
@@ -320,13 +320,12 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     /* the triangle array carries one zeroed record past the end: the search prefetches record i+1 */
     std::vector<float4> sph(n_spheres), pln((size_t)n_planes * BDPT_PLN_F4),
         tri(((size_t)n_triangles + 1) * BDPT_TRI_F4, make_float4(0.f, 0.f, 0.f, 0.f)),
-        bound((size_t)n_triangles + 1, make_float4(0.f, 0.f, 0.f, 0.f)), cull((size_t)n_triangles * BDPT_CULL_F4),
+        bound((size_t)n_triangles + 1, make_float4(0.f, 0.f, 0.f, 0.f)), cull((size_t)n_triangles * 3),
         surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     std::vector<float> cull_s(n_triangles);
     std::vector<double> big_r2(n_triangles);           /* 1.05 R^2 of each bounding sphere, for AUTO's estimate */
     double cull_c = 0.0;
-    std::memset(ctx->cull_same, 0, sizeof ctx->cull_same);
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];
         sph[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);   /* kernel0.cl:337 */
@@ -399,7 +398,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
                 const double g[3] = {(e[1] * nt[2] - e[2] * nt[1]) * f, (e[2] * nt[0] - e[0] * nt[2]) * f, (e[0] * nt[1] - e[1] * nt[0]) * f};
                 out = make_float4((float)g[0], (float)g[1], (float)g[2], (float)-(vertex[0] * g[0] + vertex[1] * g[1] + vertex[2] * g[2]));
             };
-            float4 *q3 = &cull[(size_t)i * BDPT_CULL_F4];
+            float4 *q3 = &cull[(size_t)i * 3];
             q3[0] = make_float4(n.x, n.y, n.z, (float)(A[0] * n.x + A[1] * n.y + A[2] * n.z));
             edge_plane(A, C, A, q3[1]);                                   /* dA: (p-a) x (c-a) */
             edge_plane(C, B, C, q3[2]);                                   /* dB: (p-c) x (b-c); dC is what is left of s */
@@ -408,11 +407,6 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             const double c_i = longest + a1 + theta * longest / 3.5e-6;
             const bool usable = well_shaped && theta < 1.0e-4 && std::isfinite(scale) && scale < 1.0e30 && std::isfinite(c_i) &&
                                 std::isfinite(q3[1].x + q3[1].y + q3[1].z + q3[1].w + q3[2].x + q3[2].y + q3[2].z + q3[2].w);
-            /* same plane as the triangle before (bit-identical normal and a.n): the device reuses that triangle's
-             * plane intersection */
-            if (i > 0 && (i & 31) != 0 && i < BDPT_CULL_MAX_TRIANGLES &&
-                std::memcmp(&q3[0], &cull[(size_t)(i - 1) * BDPT_CULL_F4], sizeof(float4)) == 0)
-                ctx->cull_same[i >> 5] |= 1u << (i & 31);
             if (usable) {
                 cull_s[i] = (float)scale;
                 cull_c = std::max(cull_c, c_i);
@@ -436,8 +430,42 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
     HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, bound));
-    HIP_TRY(ctx, dev_upload(ctx->d_tri_cull, cull));
-    HIP_TRY(ctx, dev_upload(ctx->d_tri_cull_s, cull_s));
+    /* the conservative test's records in the order the test walks them (bdpt_layout.h): per group of 32 triangles the
+     * pairs that share a plane (bit-identical normal and a.n, wherever in the group they are), then the rest */
+    std::vector<float4> cull_walk;
+    std::memset(ctx->cull_group, 0, sizeof ctx->cull_group);
+    if (n_triangles <= BDPT_CULL_MAX_TRIANGLES) {
+        auto bit = [](int k) { const uint32_t u = 1u << k; float f; std::memcpy(&f, &u, 4); return f; };
+        for (int base = 0; base < n_triangles; base += 32) {
+            const int cnt = std::min(32, n_triangles - base);
+            const size_t off = cull_walk.size();
+            int partner[32];
+            for (int k = 0; k < cnt; k++) partner[k] = -1;
+            int pairs = 0;
+            for (int k = 0; k < cnt; k++) {
+                if (partner[k] >= 0) continue;
+                for (int m = k + 1; m < cnt; m++)
+                    if (partner[m] < 0 && std::memcmp(&cull[(size_t)(base + k) * 3], &cull[(size_t)(base + m) * 3], sizeof(float4)) == 0) {
+                        partner[k] = m;
+                        partner[m] = k;
+                        const float4 *a = &cull[(size_t)(base + k) * 3], *b = &cull[(size_t)(base + m) * 3];
+                        cull_walk.insert(cull_walk.end(), {a[0], a[1], a[2], b[1], b[2], make_float4(cull_s[base + k], cull_s[base + m], bit(k), bit(m))});
+                        pairs++;
+                        break;
+                    }
+            }
+            int singles = 0;
+            for (int k = 0; k < cnt; k++) {
+                if (partner[k] >= 0) continue;
+                const float4 *a = &cull[(size_t)(base + k) * 3];
+                cull_walk.insert(cull_walk.end(), {a[0], a[1], a[2], make_float4(cull_s[base + k], bit(k), 0.f, 0.f)});
+                singles++;
+            }
+            ctx->cull_group[base >> 5] = (uint32_t)off | ((uint32_t)pairs << 16) | ((uint32_t)singles << 24);
+        }
+    }
+    ctx->cull_f4 = (int)cull_walk.size();
+    HIP_TRY(ctx, dev_upload(ctx->d_tri_cull, cull_walk));
     ctx->cull_c = (float)(cull_c * 1.000001);
     HIP_TRY(ctx, dev_upload(ctx->d_surf, surf));
     HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
@@ -606,7 +634,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     std::memset(&K, 0, sizeof K);
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
-    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.tri_cull_s = ctx->d_tri_cull_s; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_same, ctx->cull_same, sizeof K.scene.cull_same); K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;
@@ -701,7 +729,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
     /* AUTO: see the estimate in bdpt_upload_scene */
     if (variant == BDPT_KERNEL_AUTO)
-        variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && !ctx->auto_tiled) ? BDPT_KERNEL_TILED
+        variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && K.scene.n_triangles <= BDPT_CULL_MAX_TRIANGLES && !ctx->auto_tiled) ? BDPT_KERNEL_TILED
                   : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
     /* Sliced launch (slice_begin in bdpt_kernels.hip): runs short enough that the launch does not end with a long
      * drain, long enough that the per-run reload of the pixel state does not show (1080p Cornell box: 64 samples

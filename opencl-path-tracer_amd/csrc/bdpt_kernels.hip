@@ -237,14 +237,14 @@ extern __shared__ float4 bdpt_lds[];   /* [n_triangles*6 | (two-stage kernel: n_
 /* offsets, in float4, of the parts that follow the triangle records */
 struct LdsLayout {
     int cull, sph, pln, surf, ids;  /* cull records, spheres, planes, surface table, surface ids (uint32: triangles, spheres, planes) */
-    int n_ids;                      /* number of surface ids; the two-stage kernel's per-triangle scale factors follow them */
+    int n_ids;                      /* number of surface ids */
 };
 template <bool CULL>
 BDPT_DEV LdsLayout lds_layout(const bdpt_dev_scene &S)
 {
     LdsLayout L;
     L.cull = S.n_triangles * BDPT_TRI_F4;
-    L.sph = L.cull + (CULL ? S.n_triangles * BDPT_CULL_F4 : 0);
+    L.sph = L.cull + (CULL ? S.cull_f4 : 0);
     L.pln = L.sph + S.n_spheres;
     L.surf = L.pln + S.n_planes * BDPT_PLN_F4;
     L.ids = L.surf + S.n_surfaces * 2;
@@ -259,7 +259,7 @@ BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
     const int n_tri = S.n_triangles * BDPT_TRI_F4, n_pln = S.n_planes * BDPT_PLN_F4, n_surf = S.n_surfaces * 2;
     for (int i = threadIdx.x; i < n_tri; i += blockDim.x) bdpt_lds[i] = S.tri[i];
     if (CULL)
-        for (int i = threadIdx.x; i < S.n_triangles * BDPT_CULL_F4; i += blockDim.x) bdpt_lds[L.cull + i] = S.tri_cull[i];
+        for (int i = threadIdx.x; i < S.cull_f4; i += blockDim.x) bdpt_lds[L.cull + i] = S.tri_cull[i];
     for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) bdpt_lds[L.sph + i] = S.sph[i];
     for (int i = threadIdx.x; i < n_pln; i += blockDim.x) bdpt_lds[L.pln + i] = S.pln[i];
     for (int i = threadIdx.x; i < n_surf; i += blockDim.x) bdpt_lds[L.surf + i] = S.surf[i];
@@ -267,10 +267,6 @@ BDPT_DEV void lds_fill_scene(const bdpt_dev_scene &S)
     for (int i = threadIdx.x; i < S.n_triangles; i += blockDim.x) ids[i] = S.tri_surf[i];
     for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) ids[S.n_triangles + i] = S.sph_surf[i];
     for (int i = threadIdx.x; i < S.n_planes; i += blockDim.x) ids[S.n_triangles + S.n_spheres + i] = S.pln_surf[i];
-    if (CULL) {
-        float *cs = (float *)(ids + L.n_ids);
-        for (int i = threadIdx.x; i < S.n_triangles; i += blockDim.x) cs[i] = S.tri_cull_s[i];
-    }
     __syncthreads();
 }
 
@@ -402,11 +398,11 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     }
     /* (C + |o|_1) |d|_inf, doubled: the ray's part of the margin */
     const float ray_margin = 2.0f * (S.cull_c + fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) * fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    const float *cull_s = (const float *)(bdpt_lds + L.ids) + L.n_ids;
     for (int base = 0; base < S.n_triangles; base += 32) {
         const int cnt = min(32, S.n_triangles - base);
         uint32_t mask = 0u;
-        const uint32_t same = S.cull_same[base >> 5];
+        const uint32_t group = S.cull_group[base >> 5];
+        const float4 *c = bdpt_lds + L.cull + (group & 0xffffu);
         /* the plane part of a triangle's test: val (exact, :286), -1/val... and the approximate point on the plane */
         struct PlaneHit { float val, r, px, py, pz; };
         auto plane_part = [&](const float4 c0) {
@@ -430,28 +426,16 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m), -h.val);
             return !(z < 0.0f);
         };
-        int j = 0;
-        for (; j + 2 <= cnt; j += 2) {                                    /* stage 1, two triangles per round */
-            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
-            const float2 sc = *(const float2 *)(cull_s + base + j);       /* base and j are even, the array 8-byte aligned */
-            bool k0, k1;
-            if ((same >> (j + 1)) & 1u) {                                 /* wave-uniform: the second lies in the first one's plane */
-                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c4 = c[4], c5 = c[5];
-                const PlaneHit h = plane_part(c0);
-                k0 = kept(h, c1, c2, sc.x);
-                k1 = kept(h, c4, c5, sc.y);
-            } else {
-                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-                const PlaneHit h0 = plane_part(c0), h1 = plane_part(c3);
-                k0 = kept(h0, c1, c2, sc.x);
-                k1 = kept(h1, c4, c5, sc.y);
-            }
-            mask |= (k0 ? (1u << j) : 0u) | (k1 ? (2u << j) : 0u);
+        for (int k = (int)((group >> 16) & 0xffu); k > 0; k--, c += BDPT_CULL_PAIR_F4) {     /* stage 1: two triangles in one plane */
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+            const PlaneHit h = plane_part(c0);
+            const bool k0 = kept(h, c1, c2, c5.x), k1 = kept(h, c3, c4, c5.y);
+            mask |= (k0 ? __float_as_uint(c5.z) : 0u) | (k1 ? __float_as_uint(c5.w) : 0u);
         }
-        if (j < cnt) {
-            const float4 *c = bdpt_lds + L.cull + (base + j) * BDPT_CULL_F4;
-            const PlaneHit h = plane_part(c[0]);
-            mask |= kept(h, c[1], c[2], cull_s[base + j]) ? (1u << j) : 0u;
+        for (int k = (int)(group >> 24); k > 0; k--, c += BDPT_CULL_SINGLE_F4) {              /* ... and the others */
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            const PlaneHit h = plane_part(c0);
+            mask |= kept(h, c1, c2, c3.x) ? __float_as_uint(c3.y) : 0u;
         }
         if (COUNT) *n_cull += (unsigned long long)cnt;
         if (skip_t >= base && skip_t < base + 32) mask &= ~(1u << (skip_t - base));                   /* :436 */
@@ -1276,9 +1260,8 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
 
 size_t bdpt_lds_scene_bytes(const bdpt_dev_scene &S, bool with_cull_records)
 {
-    size_t ids = ((size_t)S.n_triangles + S.n_spheres + S.n_planes + 3) / 4;               /* uint32 ids, in float4 */
-    if (with_cull_records) ids += ((size_t)S.n_triangles + 3) / 4;                          /* float scale factors */
-    return ((size_t)S.n_triangles * (BDPT_TRI_F4 + (with_cull_records ? BDPT_CULL_F4 : 0)) + (size_t)S.n_spheres +
+    const size_t ids = ((size_t)S.n_triangles + S.n_spheres + S.n_planes + 3) / 4;         /* uint32 ids, in float4 */
+    return ((size_t)S.n_triangles * BDPT_TRI_F4 + (with_cull_records ? (size_t)S.cull_f4 : 0) + (size_t)S.n_spheres +
             (size_t)S.n_planes * BDPT_PLN_F4 + (size_t)S.n_surfaces * 2 + ids) * sizeof(float4);
 }
 

@@ -21,8 +21,8 @@
  *   triangle bound 1 x float4 : (centre c, (1 - 1e-5 - 2e-6) |c|^2 - 1.05 radius^2) of a sphere around the three
  *       vertices: what the tiled kernel streams; a ray that passes the sphere by more than
  *       rounding can explain cannot hit the triangle, and only the others read the record
- *   triangle cull 3 x float4 + 1 float : what the two-stage LDS kernel's conservative test reads, computed
- *       in double at upload and rounded (the test carries a margin for that, see closest_hit_lds2):
+ *   triangle cull : what the two-stage LDS kernel's conservative test reads, computed in double at upload and
+ *       rounded (the test carries a margin for that, see closest_hit_lds2).  Per triangle:
  *       c0 (n.x, n.y, n.z, k)       n as in q0 (the reference's normal, same bits), k = a.n
  *       c1 (g0.x, g0.y, g0.z, h0)   g_j . p + h_j = the reference's j-th edge expression (kernel0.cl:298-300)
  *       c2 (g1.x, g1.y, g1.z, h1)   for a point p of the triangle's plane, as a barycentric coordinate (1 at the
@@ -30,6 +30,12 @@
  *       s                           1 / (error of a coordinate per unit of the ray-dependent factor): in these
  *                                   units every triangle has the same margin; 0 (with g = h = 0) switches the
  *                                   test off for a triangle it cannot be trusted on (slivers)
+ *       The records are stored as the test walks them, group of 32 triangles after group (a group's candidates
+ *       are one mask word).  Within a group first the pairs of triangles that lie in one plane (bit-identical
+ *       c0: the two halves of a wall), which share the plane part of the test, six float4 each:
+ *           c0, c1 c2 of the first, c1 c2 of the second, (s first, s second, mask bit first, mask bit second)
+ *       then the other triangles, four float4 each:  c0, c1, c2, (s, mask bit, -, -).
+ *       A mask bit is 1 << (triangle index - first index of the group), kept as the bits of a float.
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
  * winning primitive only).
@@ -43,7 +49,8 @@
 #define BDPT_TRI_F4 6
 #define BDPT_PLN_F4 2
 #define BDPT_CULL_MAX_TRIANGLES 256   /* the two-stage kernel's scenes are bounded by LDS well below this */
-#define BDPT_CULL_F4 3      /* + one float per triangle in a separate array (tri_cull_s) */
+#define BDPT_CULL_PAIR_F4 6
+#define BDPT_CULL_SINGLE_F4 4
 
 struct bdpt_dev_scene {
     const float4 *sph;          /* [n_spheres] */
@@ -52,12 +59,11 @@ struct bdpt_dev_scene {
     const uint32_t *pln_surf;   /* [n_planes] */
     const float4 *tri;          /* [(n_triangles + 1) * BDPT_TRI_F4] */
     const float4 *tri_bound;    /* [n_triangles + 1] bounding spheres */
-    const float4 *tri_cull;     /* [n_triangles * BDPT_CULL_F4] records of the conservative test */
-    const float *tri_cull_s;    /* [n_triangles] */
+    const float4 *tri_cull;     /* [cull_f4] records of the conservative test; empty for scenes of more than BDPT_CULL_MAX_TRIANGLES */
+    int cull_f4;
     float cull_c;               /* scene constant of that test's margin */
-    /* bit i (word i / 32): triangle i lies in the plane of triangle i - 1 (same normal bits, same k) and is not the
-     * first of its group of 32: the two-stage kernel then reuses the plane part of triangle i - 1's test */
-    uint32_t cull_same[BDPT_CULL_MAX_TRIANGLES / 32];
+    /* per group of 32 triangles: offset of its records in tri_cull (float4, bits 0-15), pairs (16-23), others (24-31) */
+    uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32];
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;

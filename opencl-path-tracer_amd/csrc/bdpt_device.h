@@ -217,10 +217,11 @@ BDPT_DEV void test_sphere(Best &b, float4 s, int i, clm_f3 o, clm_f3 d)
 {
     clm_f3 oc = clm_sub3(o, clm_make3(s.x, s.y, s.z));
     float dot1 = clm_dot3(d, oc);                                                    /* :331 */
-    if (dot1 > 0) return;                                                            /* :333 */
     float d2 = clm_dot3(oc, oc);                                                     /* :336 */
     float disc = dot1 * dot1 - d2 + s.w;                                             /* :337 */
-    if (disc < 0) return;                                                            /* :341 */
+    /* one branch for the two culls: a wavefront nearly always has a lane that passes the first, and each
+     * branch level costs about as much as the six operations it would skip */
+    if (dot1 > 0 || disc < 0) return;                                                /* :333, :341 */
     float tA = -dot1 - clm_sqrt(disc);                                               /* :344-347 */
     if (tA < 0) return;                                                              /* :350 */
     clm_f3 p = clm_mad3(tA, d, o);                                                   /* :354 */
@@ -382,10 +383,11 @@ BDPT_DEV void connection(const bdpt_kargs &K, const Hit &eye, const Hit &vis, cl
                          clm_f3 test_dir, const float acc[4], float inv_imp, float out[4])
 {
     out[0] = out[1] = out[2] = out[3] = 0.0f;
-    if (eye.type != vis.type || eye.idx != vis.idx) return;                          /* :712 */
     const clm_f3 gap = clm_sub3(eye.pos, vis.pos);
-    if (!(clm_dot3(gap, gap) < K.same_point_d2)) return;                             /* :714, length < 0.0001f without the root */
-    if (!(clm_dot3(eye.n, vis.n) > 0)) return;
+    /* one branch for the three conditions: each is a few operations, a branch level costs about as much */
+    if (eye.type != vis.type || eye.idx != vis.idx ||                                /* :712 */
+        !(clm_dot3(gap, gap) < K.same_point_d2) ||                                   /* :714, length < 0.0001f without the root */
+        !(clm_dot3(eye.n, vis.n) > 0)) return;
     clm_f3 pv = clm_sub3(vis.pos, vert_pos);                                         /* :716 */
     float r2 = pv.x * pv.x + pv.y * pv.y + pv.z * pv.z;
     float sf = (K.falloff == BDPT_FALLOFF_INV_SQ_PLUS_C) ? clm_div(1.0f, K.falloff_c + r2)

@@ -238,6 +238,8 @@ int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, 
  * 0 (the default): chosen per launch (up to 16 runs of at least 32 samples; one sample per run for scenes of many
  * triangles); 1: one run. */
 int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks);
+/* runs per tile the last render call asked its launch for (1 = unsliced) */
+int bdpt_last_launch_chunks(const bdpt_ctx *ctx);
 
 /* Interop with a caller that owns device memory and streams (torch):
  * render on `hip_stream` (NULL = the context's own stream), and accumulate into

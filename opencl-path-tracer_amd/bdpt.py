@@ -105,6 +105,7 @@ lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_launch_chunks.argtypes = [_vp, C.c_int]
+lib.bdpt_last_launch_chunks.argtypes = [_vp]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
 lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
@@ -427,6 +428,9 @@ class Context:
     def set_launch_chunks(self, chunks):
         """Runs per tile of a render call (0 = chosen per launch, 1 = unsliced); never changes a result."""
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
+
+    def last_launch_chunks(self):
+        return lib.bdpt_last_launch_chunks(self._h)
 
     def set_sample_offset(self, first_sample):
         self._check(lib.bdpt_set_sample_offset(self._h, first_sample))

@@ -43,6 +43,7 @@ struct bdpt_ctx {
     bool counters_on = false;
     bool auto_tiled = false;            /* AUTO prefers the tiled kernel for this scene even if it fits LDS */
     int last_variant = 0;
+    int last_chunks = 1;
 
     /* host copies needed after upload */
     std::vector<bdpt_sphere> spheres;
@@ -756,6 +757,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;
     ctx->last_variant = variant;
+    ctx->last_chunks = K.n_chunks;
     ctx->num_samples += spp;                                              /* main.cpp:131 */
     return BDPT_OK;
 }
@@ -791,6 +793,7 @@ int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks)
 }
 
 int bdpt_last_launch_variant(const bdpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
+int bdpt_last_launch_chunks(const bdpt_ctx *ctx) { return ctx ? ctx->last_chunks : 0; }
 
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms)
 {

@@ -428,21 +428,49 @@ BDPT_DEV constexpr uint32_t lcg_pow(int e)
     return m;
 }
 
+/* bit k set = roulette draw k of the sample (k = 0 .. N-1) ends the light subpath there; x = that draw of k = 0 */
+template <int N>
+BDPT_DEV uint32_t roulette_stops(uint32_t x, uint32_t step, uint32_t fate_above)
+{
+    uint32_t stops = 0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        stops |= x > fate_above ? (1u << k) : 0u;                                    /* :788 */
+        x *= step;
+    }
+    return stops;
+}
+
 /* Number of light-subpath vertices roulette allows a sample; same cost for every lane.  A sample
  * draws 8 numbers before its first roulette draw (1 discarded, 2 pixel jitter, 2 light point, 3 first
  * cone sample) and 3 between one roulette draw and the next, so roulette draw k is the generator's
- * output number 9+4k: the start state times 48271^(9+4k). */
+ * output number 9+4k: the start state times 48271^(9+4k).  Straight-line code for the subpath lengths a
+ * STRIDED launch can have (at most seven vertices: the draws of a sample must fit its stride). */
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
     const bool five = sampler_draws_four(K.sampler);           /* one more draw per vertex: 10 + 5k */
     const uint32_t step = five ? lcg_pow(5) : lcg_pow(4);
-    int cls = K.max_l;
-    uint32_t x = start_state * (five ? lcg_pow(10) : lcg_pow(9));
-    for (int k = 0; k + 1 < K.max_l; k++) {
-        cls = (x > K.fate_above && cls == K.max_l) ? k + 1 : cls;                    /* :788 */
-        x *= step;
+    const uint32_t x = start_state * (five ? lcg_pow(10) : lcg_pow(9));
+    uint32_t stops;
+    switch (K.max_l) {                                         /* wave-uniform */
+    case 1: stops = 0u; break;
+    case 2: stops = roulette_stops<1>(x, step, K.fate_above); break;
+    case 3: stops = roulette_stops<2>(x, step, K.fate_above); break;
+    case 4: stops = roulette_stops<3>(x, step, K.fate_above); break;
+    case 5: stops = roulette_stops<4>(x, step, K.fate_above); break;
+    case 6: stops = roulette_stops<5>(x, step, K.fate_above); break;
+    case 7: stops = roulette_stops<6>(x, step, K.fate_above); break;
+    default: {
+        stops = 0u;
+        uint32_t y = x;
+        for (int k = 0; k + 1 < K.max_l && k < 31; k++) {
+            stops |= y > K.fate_above ? (1u << k) : 0u;
+            y *= step;
+        }
     }
-    return cls;
+    }
+    if (K.max_l <= 32) stops |= 1u << (K.max_l - 1);           /* the walk never has more than max_l vertices */
+    return stops ? __builtin_ctz(stops) + 1 : K.max_l;
 }
 
 /* start state of the first sample of this launch (STRIDED) */
@@ -469,6 +497,17 @@ BDPT_DEV constexpr uint32_t stride_inv_pow2(int j)
 }
 static_assert(stride_inv_pow2(0) * kSampleStride == 1u, "stride inverse");
 
+/* powers 0..32 of that inverse */
+struct StrideInvPow { uint32_t v[33]; };
+BDPT_DEV constexpr StrideInvPow make_stride_inv_pow()
+{
+    StrideInvPow t{};
+    uint32_t p = 1u;
+    for (int i = 0; i < 33; i++) { t.v[i] = p; p *= stride_inv_pow2(0); }
+    return t;
+}
+static __device__ const StrideInvPow kStrideInvPow = make_stride_inv_pow();
+
 /*
  * false when the launch has no more samples for this pixel; otherwise start = start state (STRIDED).
  * seed_w = the pixel's seed word, wanted again when a lane restarts at sample 0 for the next class.
@@ -488,28 +527,29 @@ BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *
         c.head++;
         return true;
     }
-    for (;;) {
+    for (;;) {                                               /* one round: selects, no per-lane branches */
         const bool starved = c.pending == 0u;
-        if (starved && c.head >= K.spp && c.cls >= 1) {      /* no more samples of this class: next class */
-            c.cls--;
-            c.head = 0;
-            c.st_head = cursor_first_state(K, *seed_w);
+        const bool next_class = starved && c.head >= K.spp && c.cls >= 1;   /* no more samples of this class */
+        if (__builtin_amdgcn_ballot_w64(next_class) != 0) {
+            asm volatile("");                                /* a real branch: a handful of times per launch */
+            if (next_class) {
+                c.cls--;
+                c.head = 0;
+                c.st_head = cursor_first_state(K, *seed_w);
+            }
         }
         const bool done = c.cls < 1;
         if (__builtin_amdgcn_ballot_w64(starved && !done) == 0) break;
-        if (!done && c.head < K.spp && (c.pending >> 31) == 0u) {
-            c.pending = (c.pending << 1) | (roulette_class(K, c.st_head) == c.cls ? 1u : 0u);
-            c.head++;
-            c.st_head *= kSampleStride;
-        }
+        const bool advance = !done && c.head < K.spp && (c.pending >> 31) == 0u;
+        const uint32_t found = roulette_class(K, c.st_head) == c.cls ? 1u : 0u;
+        c.pending = advance ? ((c.pending << 1) | found) : c.pending;
+        c.head += advance ? 1 : 0;
+        c.st_head = advance ? c.st_head * kSampleStride : c.st_head;
     }
     if (c.cls < 1) return false;
     const int i = 31 - __builtin_clz(c.pending);             /* oldest pending sample: index head-1-i */
     c.pending &= ~(1u << i);
-    uint32_t st = c.st_head * stride_inv_pow2(0);
-#pragma unroll
-    for (int j = 0; j < 5; j++) st *= ((i >> j) & 1) ? stride_inv_pow2(j) : 1u;
-    start = st;
+    start = c.st_head * kStrideInvPow.v[i + 1];              /* back from sample head to sample head-1-i */
     return true;
 }
 

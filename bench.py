@@ -271,7 +271,7 @@ def main():
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
             "frac_reference_formulation": round(flops_ref / avg_s / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP,
+            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (ctx.last_launch_chunks() - 1),
             "traffic_source": None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run"),
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "flops_per_launch_reference_formulation": flops_ref,
             "rays_traced": rays, "rays_reference_formulation": rays_ref, "paths_full": full, "paths_early": early,

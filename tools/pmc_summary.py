@@ -7,6 +7,8 @@ executed_tflops = FP32 vector flops the lanes actually performed / kernel time:
   (2 * FMA + MUL + ADD wave-instructions) * 64 lanes * lane utilisation,
   lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)   (both count 4-cycle units over all VALU work).
 valu_issue_busy = VALU wave-instructions * 2 cycles / (SIMDs * kernel clocks), kernel clocks = GRBM_GUI_ACTIVE / 8 XCDs.
+simd_cycles_per_valu_inst = SIMDs * kernel clocks / VALU wave-instructions (tools/valu_issue.hip: 1.36 for back-to-back
+fma at six wavefronts per SIMD); wavefronts_per_simd_mean = SQ_WAVE_CYCLES (4-cycle units) * 4 / (SIMDs * kernel clocks).
 """
 import json
 import os
@@ -33,6 +35,10 @@ entry = {
     "executed_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 2),
     "executed_frac_of_157.3": round(flops / (kernel_ms * 1e-3) / 1e12 / 157.3, 3),
     "valu_issue_busy": round(c["SQ_INSTS_VALU"] * 2.0 / (1024 * clocks), 3),
+    "simd_cycles_per_valu_inst": round(1024 * clocks / c["SQ_INSTS_VALU"], 2),
+    "wavefronts_per_simd_mean": round(c["SQ_WAVE_CYCLES"] * 4.0 / (1024 * clocks), 2),
+    "salu_per_valu": round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3) if "SQ_INSTS_SALU" in c else None,
+    "branch_per_valu": round(c["SQ_INSTS_BRANCH"] / c["SQ_INSTS_VALU"], 3) if "SQ_INSTS_BRANCH" in c else None,
     "lds_array_busy": round(c["SQ_LDS_IDX_ACTIVE"] / (256 * clocks), 3) if "SQ_LDS_IDX_ACTIVE" in c else None,
     "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
     "wave_cycles_waiting_fraction": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),

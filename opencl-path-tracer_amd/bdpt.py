@@ -106,6 +106,7 @@ lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_launch_chunks.argtypes = [_vp, C.c_int]
 lib.bdpt_last_launch_chunks.argtypes = [_vp]
+lib.bdpt_two_stage_record_counts.argtypes = [_vp, C.POINTER(C.c_int)]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
 lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
@@ -428,6 +429,12 @@ class Context:
     def set_launch_chunks(self, chunks):
         """Runs per tile of a render call (0 = chosen per launch, 1 = unsliced); never changes a result."""
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
+
+    def two_stage_record_counts(self):
+        """(parallelogram pairs, other coplanar pairs, single triangles) of the two-stage kernel's conservative test."""
+        out = (C.c_int * 3)()
+        self._check(lib.bdpt_two_stage_record_counts(self._h, out))
+        return tuple(out)
 
     def last_launch_chunks(self):
         return lib.bdpt_last_launch_chunks(self._h)

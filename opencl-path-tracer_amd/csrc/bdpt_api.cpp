@@ -325,6 +325,8 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         surf((size_t)n_surfaces * 2);
     std::vector<uint32_t> sph_s(n_spheres), pln_s(n_planes), tri_s(n_triangles);
     std::vector<float> cull_s(n_triangles);
+    std::vector<float4> cull_third(n_triangles);       /* third coordinate plane and longest edge of each triangle */
+    std::vector<double> cull_len(n_triangles);
     std::vector<double> big_r2(n_triangles);           /* 1.05 R^2 of each bounding sphere, for AUTO's estimate */
     double cull_c = 0.0;
     for (int i = 0; i < n_spheres; i++) {
@@ -403,6 +405,8 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             q3[0] = make_float4(n.x, n.y, n.z, (float)(A[0] * n.x + A[1] * n.y + A[2] * n.z));
             edge_plane(A, C, A, q3[1]);                                   /* dA: (p-a) x (c-a) */
             edge_plane(C, B, C, q3[2]);                                   /* dB: (p-c) x (b-c); dC is what is left of s */
+            edge_plane(B, A, B, cull_third[i]);                           /* dC: (p-b) x (a-b), for the pairing below */
+            cull_len[i] = longest;
             double a1 = 0.0;
             for (const double *v : {A, B, C}) a1 = std::max(a1, std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]));
             const double c_i = longest + a1 + theta * longest / 3.5e-6;
@@ -413,7 +417,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
                 cull_c = std::max(cull_c, c_i);
             } else {                                                      /* every coordinate 0: never below the (negative) bound */
                 cull_s[i] = 0.0f;
-                q3[1] = q3[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                q3[1] = q3[2] = cull_third[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -431,30 +435,75 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
     HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, bound));
-    /* the conservative test's records in the order the test walks them (bdpt_layout.h): per group of 32 triangles the
-     * pairs that share a plane (bit-identical normal and a.n, wherever in the group they are), then the rest */
+    /* The conservative test's records in the order the test walks them (bdpt_layout.h), per group of 32 triangles:
+     * the pairs that share a plane (equal normal and a.n, wherever in the group they are) -- first those
+     * that are the two halves of a parallelogram, whose second triangle needs no planes of its own -- then the rest. */
     std::vector<float4> cull_walk;
     std::memset(ctx->cull_group, 0, sizeof ctx->cull_group);
     if (n_triangles <= BDPT_CULL_MAX_TRIANGLES) {
         auto bit = [](int k) { const uint32_t u = 1u << k; float f; std::memcpy(&f, &u, 4); return f; };
+        /* Triangles i and j halves of one parallelogram, cut along an edge they share?  Then, with u and v the
+         * first one's coordinates that vanish on its two other edges (scaled: s at the opposite vertex), the
+         * second one's coordinates are s - u, s - v and u + v - s.  Writes u's and v's planes. */
+        auto parallelogram = [&](int i, int j, float4 &pu, float4 &pv) {
+            if (cull_s[i] == 0.0f || std::memcmp(&cull_s[i], &cull_s[j], 4) != 0) return false;
+            const float *vi[3] = {triangles[i].p0, triangles[i].p1, triangles[i].p2};   /* a, b, c */
+            const float *vj[3] = {triangles[j].p0, triangles[j].p1, triangles[j].p2};
+            int shared_i[3] = {0, 0, 0}, shared_j[3] = {0, 0, 0}, n_shared = 0;
+            for (int x = 0; x < 3; x++)
+                for (int y = 0; y < 3; y++)
+                    if (!shared_j[y] && !shared_i[x] && std::memcmp(vi[x], vj[y], 3 * sizeof(float)) == 0) { shared_i[x] = shared_j[y] = 1; n_shared++; }
+            if (n_shared != 2) return false;
+            int oi = 0, oj = 0;                                             /* the vertices that are not shared */
+            for (int x = 0; x < 3; x++) { if (!shared_i[x]) oi = x; if (!shared_j[x]) oj = x; }
+            const float *s1 = vi[(oi + 1) % 3], *s2 = vi[(oi + 2) % 3];
+            const double tol = 2.0e-7 * cull_len[i];
+            for (int k = 0; k < 3; k++)
+                if (std::fabs(((double)vi[oi][k] + vj[oj][k]) - ((double)s1[k] + s2[k])) > tol) return false;
+            /* planes of triangle i: cull[3i+1] vanishes on edge a-c, cull[3i+2] on c-b, cull_third[i] on b-a; the
+             * shared edge is the one opposite vertex oi (a: c-b, b: a-c, c: b-a): take the other two */
+            const float4 on_ac = cull[(size_t)i * 3 + 1], on_cb = cull[(size_t)i * 3 + 2], on_ba = cull_third[i];
+            if (oi == 0) { pu = on_ac; pv = on_ba; }
+            else if (oi == 1) { pu = on_cb; pv = on_ba; }
+            else { pu = on_ac; pv = on_cb; }
+            /* check the prediction where it matters: at the second triangle's corners its coordinates are (s, 0, 0) in some order */
+            const double sd = cull_s[i];
+            for (int y = 0; y < 3; y++) {
+                const double u = (double)pu.x * vj[y][0] + (double)pu.y * vj[y][1] + (double)pu.z * vj[y][2] + pu.w;
+                const double v = (double)pv.x * vj[y][0] + (double)pv.y * vj[y][1] + (double)pv.z * vj[y][2] + pv.w;
+                double co[3] = {sd - u, sd - v, u + v - sd};
+                std::sort(co, co + 3);
+                if (std::fabs(co[0]) > 1.0e-4 * sd || std::fabs(co[1]) > 1.0e-4 * sd || std::fabs(co[2] - sd) > 1.0e-4 * sd) return false;
+            }
+            return true;
+        };
+        /* Same normal and same a.n, as numbers: a zero may differ in sign between two triangles of one plane (it comes
+         * out of a cross product), which changes d.n and k - o.n only where they are zero themselves -- a ray in the
+         * plane, which hits neither triangle.  NaNs never compare equal. */
+        auto same_plane = [](const float4 &a, const float4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; };
         for (int base = 0; base < n_triangles; base += 32) {
             const int cnt = std::min(32, n_triangles - base);
             const size_t off = cull_walk.size();
             int partner[32];
             for (int k = 0; k < cnt; k++) partner[k] = -1;
-            int pairs = 0;
+            std::vector<float4> quad_rec, pair_rec;
             for (int k = 0; k < cnt; k++) {
                 if (partner[k] >= 0) continue;
                 for (int m = k + 1; m < cnt; m++)
-                    if (partner[m] < 0 && std::memcmp(&cull[(size_t)(base + k) * 3], &cull[(size_t)(base + m) * 3], sizeof(float4)) == 0) {
+                    if (partner[m] < 0 && same_plane(cull[(size_t)(base + k) * 3], cull[(size_t)(base + m) * 3])) {
                         partner[k] = m;
                         partner[m] = k;
                         const float4 *a = &cull[(size_t)(base + k) * 3], *b = &cull[(size_t)(base + m) * 3];
-                        cull_walk.insert(cull_walk.end(), {a[0], a[1], a[2], b[1], b[2], make_float4(cull_s[base + k], cull_s[base + m], bit(k), bit(m))});
-                        pairs++;
+                        float4 pu, pv;
+                        if (parallelogram(base + k, base + m, pu, pv))
+                            quad_rec.insert(quad_rec.end(), {a[0], pu, pv, make_float4(cull_s[base + k], bit(k), bit(m), 0.f)});
+                        else
+                            pair_rec.insert(pair_rec.end(), {a[0], a[1], a[2], b[1], b[2], make_float4(cull_s[base + k], cull_s[base + m], bit(k), bit(m))});
                         break;
                     }
             }
+            cull_walk.insert(cull_walk.end(), quad_rec.begin(), quad_rec.end());
+            cull_walk.insert(cull_walk.end(), pair_rec.begin(), pair_rec.end());
             int singles = 0;
             for (int k = 0; k < cnt; k++) {
                 if (partner[k] >= 0) continue;
@@ -462,7 +511,8 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
                 cull_walk.insert(cull_walk.end(), {a[0], a[1], a[2], make_float4(cull_s[base + k], bit(k), 0.f, 0.f)});
                 singles++;
             }
-            ctx->cull_group[base >> 5] = (uint32_t)off | ((uint32_t)pairs << 16) | ((uint32_t)singles << 24);
+            ctx->cull_group[base >> 5] = (uint32_t)off | ((uint32_t)(quad_rec.size() / BDPT_CULL_QUAD_F4) << 16) |
+                                         ((uint32_t)(pair_rec.size() / BDPT_CULL_PAIR_F4) << 21) | ((uint32_t)singles << 26);
         }
     }
     ctx->cull_f4 = (int)cull_walk.size();
@@ -794,6 +844,18 @@ int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks)
 
 int bdpt_last_launch_variant(const bdpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
 int bdpt_last_launch_chunks(const bdpt_ctx *ctx) { return ctx ? ctx->last_chunks : 0; }
+
+int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[3])
+{
+    if (!ctx || !out) return BDPT_ERR_INVALID;
+    out[0] = out[1] = out[2] = 0;
+    for (int g = 0; g * 32 < ctx->n_triangles && g < BDPT_CULL_MAX_TRIANGLES / 32; g++) {
+        out[0] += (int)((ctx->cull_group[g] >> 16) & 0x1fu);
+        out[1] += (int)((ctx->cull_group[g] >> 21) & 0x1fu);
+        out[2] += (int)(ctx->cull_group[g] >> 26);
+    }
+    return BDPT_OK;
+}
 
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms)
 {

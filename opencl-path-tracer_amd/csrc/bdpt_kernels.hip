@@ -426,13 +426,24 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m), -h.val);
             return !(z < 0.0f);
         };
-        for (int k = (int)((group >> 16) & 0xffu); k > 0; k--, c += BDPT_CULL_PAIR_F4) {     /* stage 1: two triangles in one plane */
+        for (int k = (int)((group >> 16) & 0x1fu); k > 0; k--, c += BDPT_CULL_QUAD_F4) {     /* stage 1: the two halves of a parallelogram */
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            const PlaneHit h = plane_part(c0);
+            const float u = __builtin_fmaf(h.pz, c1.z, __builtin_fmaf(h.py, c1.y, __builtin_fmaf(h.px, c1.x, c1.w)));
+            const float v = __builtin_fmaf(h.pz, c2.z, __builtin_fmaf(h.py, c2.y, __builtin_fmaf(h.px, c2.x, c2.w)));
+            const float su = c3.x - u, sv = c3.x - v, w = su - v;            /* first: u, v, w; second: s - u, s - v, -w */
+            const float m0 = __builtin_fminf(__builtin_fminf(u, v), w), m1 = __builtin_fminf(__builtin_fminf(su, sv), -w);
+            const float z0 = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m0), -h.val);
+            const float z1 = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m1), -h.val);
+            mask |= (!(z0 < 0.0f) ? __float_as_uint(c3.y) : 0u) | (!(z1 < 0.0f) ? __float_as_uint(c3.z) : 0u);
+        }
+        for (int k = (int)((group >> 21) & 0x1fu); k > 0; k--, c += BDPT_CULL_PAIR_F4) {     /* ... two triangles in one plane */
             const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
             const PlaneHit h = plane_part(c0);
             const bool k0 = kept(h, c1, c2, c5.x), k1 = kept(h, c3, c4, c5.y);
             mask |= (k0 ? __float_as_uint(c5.z) : 0u) | (k1 ? __float_as_uint(c5.w) : 0u);
         }
-        for (int k = (int)(group >> 24); k > 0; k--, c += BDPT_CULL_SINGLE_F4) {              /* ... and the others */
+        for (int k = (int)(group >> 26); k > 0; k--, c += BDPT_CULL_SINGLE_F4) {              /* ... and the others */
             const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
             const PlaneHit h = plane_part(c0);
             mask |= kept(h, c1, c2, c3.x) ? __float_as_uint(c3.y) : 0u;

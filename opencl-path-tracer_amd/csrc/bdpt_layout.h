@@ -35,6 +35,10 @@
  *       c0: the two halves of a wall), which share the plane part of the test, six float4 each:
  *           c0, c1 c2 of the first, c1 c2 of the second, (s first, s second, mask bit first, mask bit second)
  *       then the other triangles, four float4 each:  c0, c1, c2, (s, mask bit, -, -).
+ *       In front of those, the pairs that are the two halves of a parallelogram, four float4 each:
+ *           c0, u, v, (s, mask bit first, mask bit second, -)
+ *       u and v are the first triangle's coordinate planes that vanish on its two edges other than the shared
+ *       one; the first triangle's coordinates are u, v, s - u - v, the second one's s - u, s - v, u + v - s.
  *       A mask bit is 1 << (triangle index - first index of the group), kept as the bits of a float.
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
@@ -49,6 +53,7 @@
 #define BDPT_TRI_F4 6
 #define BDPT_PLN_F4 2
 #define BDPT_CULL_MAX_TRIANGLES 256   /* the two-stage kernel's scenes are bounded by LDS well below this */
+#define BDPT_CULL_QUAD_F4 4
 #define BDPT_CULL_PAIR_F4 6
 #define BDPT_CULL_SINGLE_F4 4
 
@@ -62,7 +67,8 @@ struct bdpt_dev_scene {
     const float4 *tri_cull;     /* [cull_f4] records of the conservative test; empty for scenes of more than BDPT_CULL_MAX_TRIANGLES */
     int cull_f4;
     float cull_c;               /* scene constant of that test's margin */
-    /* per group of 32 triangles: offset of its records in tri_cull (float4, bits 0-15), pairs (16-23), others (24-31) */
+    /* per group of 32 triangles: offset of its records in tri_cull (float4, bits 0-15), parallelograms (16-20),
+     * other coplanar pairs (21-25), other triangles (26-31) */
     uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32];
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */

@@ -403,6 +403,62 @@ def test_two_stage_kernel_conservative_test_never_drops_a_hit(bdpt, oracle, seed
     ctx.close()
 
 
+def _quad_walls(bdpt, n_quads, n_loose, seed):
+    """Cornell box plus parallelograms of every size, two thirds of them rectangles with sides along the axes (the
+    others seldom give both halves the same plane bit for bit), each cut into two triangles along either diagonal, with the vertices in any rotation and either winding (the halves of some wound differently, so that
+    their normals differ), a few with the fourth corner nudged off the parallelogram within its plane, and loose triangles between."""
+    rng = np.random.default_rng(seed)
+    sc = bdpt.Scene.cornell()
+    tris = []
+    for q in range(n_quads):
+        size = 10.0 ** rng.uniform(-1.5, 0.8)
+        p = rng.uniform(-2.5, 2.5, 3).astype(np.float32)
+        e1 = (rng.standard_normal(3) * size).astype(np.float32)
+        e2 = (rng.standard_normal(3) * size).astype(np.float32)
+        if q % 3 != 0:                                                  # axis-aligned: both halves get the same normal and a.n bit for bit
+            i, j = rng.choice(3, 2, replace=False)
+            e1 = np.zeros(3, np.float32); e1[i] = np.float32(rng.choice([-1, 1]) * size * rng.uniform(0.3, 3.0))
+            e2 = np.zeros(3, np.float32); e2[j] = np.float32(rng.choice([-1, 1]) * size * rng.uniform(0.3, 3.0))
+        corner = [p, p + e1, p + e1 + e2, p + e2]                      # float32 sums: the fourth corner is rounded
+        if q % 5 == 4:                                                  # in its plane: from a rounding error's worth to a plain trapezoid
+            corner[2] = (corner[2] + e1 * np.float32(10.0 ** rng.uniform(-7.5, -0.5))).astype(np.float32)
+        halves = ([(0, 1, 2), (0, 2, 3)], [(1, 2, 3), (1, 3, 0)])[int(rng.integers(2))]
+        flip_both = rng.random() < 0.5
+        for k, h in enumerate(halves):
+            r = int(rng.integers(3))
+            h = h[r:] + h[:r]
+            if flip_both != (k == 1 and q % 7 == 6):
+                h = (h[0], h[2], h[1])
+            tris.append([corner[i] for i in h])
+        for _ in range(int(rng.integers(0, 2)) if n_loose else 0):
+            c = rng.uniform(-2.8, 2.8, 3)
+            tris.append([c, c + rng.standard_normal(3) * 0.5, c + rng.standard_normal(3) * 0.5])
+            n_loose -= 1
+    tri = np.zeros(len(tris), bdpt.triangle_dtype)
+    for i, t in enumerate(tris):
+        tri["p0"][i, :3], tri["p1"][i, :3], tri["p2"][i, :3] = t
+    tri["surface"] = rng.choice([0, 1, 3, 4], len(tris))
+    sc.triangles = np.concatenate([sc.triangles, tri])
+    return sc
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_two_stage_kernel_parallelogram_pairs_never_drop_a_hit(bdpt, oracle, seed):
+    """The two halves of a parallelogram share the plane part and the coordinate planes of the conservative test (the
+    second half's coordinates are derived from the first one's).  Every id, count and bit as the oracle, for
+    parallelograms of all shapes, cuts, windings, and near-misses of the shape."""
+    scene = _quad_walls(bdpt, 34, 16, seed)
+    W, H = 64, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_LDS2)
+    quads, pairs, singles = ctx.two_stage_record_counts()
+    assert quads >= 16 and pairs >= 2 and singles >= 16 and 2 * (quads + pairs) + singles == len(scene.triangles), (quads, pairs, singles)
+    for s in range(3):
+        ctx.render(3)
+        oracle.render(st, scene, scene.camera, p, 3, n_threads=8)
+        _compare(bdpt, ctx, st, "two-stage, parallelograms %d launch %d:" % (seed, s))
+    ctx.close()
+
+
 def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
     """AUTO: the Cornell box (12 wall-sized triangles) stays in LDS (two-stage kernel), also with a few more triangles; a few dozen
     small triangles tip it to the tiled kernel with its bounding-sphere test; a scene too large for LDS always."""

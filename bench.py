@@ -34,7 +34,8 @@ sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
 F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flops per primitive test / per ray
 F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
-F_CULL = {4: 17, 5: 30}         # flops of the cheap test in front of the triangle test: bounding sphere (TILED), slab test (LDS2)
+F_CULL = {4: 15, 5: 29}         # flops of the cheap test in front of the triangle test: bounding sphere (TILED: 7 fma + compare);
+                                # conservative plane test (LDS2), for two triangles that share only the plane; see f_cull_lds2
 
 
 def recorded(name, key):
@@ -259,9 +260,16 @@ def main():
         f_ray = F_SPHERE * n_s + F_PLANE * n_p + F_TRIANGLE * n_t + F_RAY_FIXED
         f_paths = full * F_PATH_FULL + early * F_PATH_EARLY
         flops_ref = rays_ref * f_ray + f_paths
+        f_cull = F_CULL.get(variant)
+        if variant == 5:
+            # per cull test: the plane part (19 flops) is shared by the two triangles of a pair; a triangle's own part
+            # is 19 flops (two coordinate planes, the third coordinate, minimum, margin, compare), 12.5 for each half
+            # of a parallelogram, which shares the coordinate planes as well
+            quads, pairs, singles = ctx.two_stage_record_counts()
+            f_cull = (quads * 44 + pairs * 57 + singles * 38) / max(1, 2 * quads + 2 * pairs + singles)
         if variant in F_CULL:
             # a cheap conservative test decides most (ray, triangle) pairs; price the tests that were run
-            flops = rays * (F_SPHERE * n_s + F_PLANE * n_p + F_RAY_FIXED) + n_cull * F_CULL[variant] + n_exact * F_TRIANGLE + f_paths
+            flops = int(rays * (F_SPHERE * n_s + F_PLANE * n_p + F_RAY_FIXED) + n_cull * f_cull + n_exact * F_TRIANGLE + f_paths)
         else:
             flops = rays * f_ray + f_paths
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
@@ -279,7 +287,7 @@ def main():
             "note": ("frac prices the tests the timed launch ran (rays traced x per-primitive flops of the reference's tests; for "
                      "kernels with a cheap conservative test in front of the triangle test: cull tests x %s + triangle tests "
                      "actually run x 113); frac_reference_formulation prices every ray and every (ray, primitive) pair of "
-                     "the reference's formulation, which a kernel that culls does not execute -- it may exceed 1" % F_CULL.get(variant, "n/a")),
+                     "the reference's formulation, which a kernel that culls does not execute -- it may exceed 1" % ("n/a" if f_cull is None else "%.1f" % f_cull)),
         }
         executed = recorded("pmc_summary.json", "%s/%s" % (args.workload, variant_name))
         if executed is not None:

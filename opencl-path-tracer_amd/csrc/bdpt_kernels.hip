@@ -481,6 +481,28 @@ BDPT_DEV float4 surface_row(const bdpt_dev_scene &S, uint32_t i)
     return S.surf[i];
 }
 
+/*
+ * The eye vertex of a sample is needed once per light-subpath vertex (connection direction, connection test) and
+ * at the end (its colour), with closest-hit searches in between that want every register: the LDS kernels keep
+ * it in three float4 of LDS per lane, behind the scene (48-byte stride: 16 lanes cover the 64 banks exactly).
+ * Volatile accesses: each read is a read, not a value the compiler may keep in a register across the searches.
+ */
+#define BDPT_PARK_F4 3
+template <int MODE>
+BDPT_DEV volatile float4 *lane_park(const bdpt_dev_scene &S)
+{
+    const LdsLayout L = MODE == MODE_LDS2 ? lds_layout<true>(S) : lds_layout<false>(S);
+    return bdpt_lds + L.ids + L.n_ids / 4 + (int)threadIdx.x * BDPT_PARK_F4;
+}
+BDPT_DEV void park_store(volatile float4 *p, float x, float y, float z, float w)
+{
+    p->x = x; p->y = y; p->z = z; p->w = w;
+}
+BDPT_DEV float4 park_load(const volatile float4 *p)
+{
+    return make_float4(p->x, p->y, p->z, p->w);
+}
+
 /* SCATTERED: the rays of a wavefront point in unrelated directions (every ray but the eye ray) */
 template <int MODE, bool SCATTERED, bool COUNT>
 BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx, Tally &T)
@@ -518,6 +540,14 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         return true;
     }
 
+    const bool parked = MODE != MODE_DIRECT;
+    volatile float4 *park = parked ? lane_park<MODE>(S) : nullptr;
+    if (parked) {
+        park_store(park + 0, eye.pos.x, eye.pos.y, eye.pos.z, __int_as_float(eye.type));
+        park_store(park + 1, eye.n.x, eye.n.y, eye.n.z, __int_as_float(eye.idx));
+        park_store(park + 2, eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w);
+    }
+
     clm_f3 vpos, vn;                                                      /* current light-subpath vertex */
     sample_light(w, draws, K, vpos, vn);                                  /* :669 */
     int vtype = K.light_origin_type, vidx = K.light_origin_index;
@@ -529,12 +559,20 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     clm_f3 incoming = clm_make3(0.0f, 0.0f, 0.0f);                        /* :659 */
     for (int lti = 0; lti < K.max_l; lti++) {                             /* :696 */
         if (ALL_RAYS || !K.indirect_only || lti != 0) {                   /* INDIRECT_ONLY drops the light's own connection (:752-755) */
-            clm_f3 tdir = clm_normalize3(clm_sub3(eye.pos, vpos));        /* :699 */
+            clm_f3 to = eye.pos;
+            if (parked) { const float4 e0 = park_load(park + 0); to = clm_make3(e0.x, e0.y, e0.z); }
+            clm_f3 tdir = clm_normalize3(clm_sub3(to, vpos));             /* :699 */
             Hit vis = trace_one<MODE, true, COUNT>(S, vpos, tdir, vtype, vidx, T);  /* :705 */
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
             float contrib[4];
-            connection(K, eye, vis, vpos, vn, tdir, acc, inv_pre_factor(K, lti, pre), contrib);
+            Hit at = eye;                                                 /* what the connection term reads: type, idx, pos, n */
+            if (parked) {
+                const float4 e0 = park_load(park + 0), e1 = park_load(park + 1);
+                at.pos = clm_make3(e0.x, e0.y, e0.z); at.type = __float_as_int(e0.w);
+                at.n = clm_make3(e1.x, e1.y, e1.z); at.idx = __float_as_int(e1.w);
+            }
+            connection(K, at, vis, vpos, vn, tdir, acc, inv_pre_factor(K, lti, pre), contrib);
             if (!K.indirect_only || lti != 0) {                           /* :752-755 */
 #pragma unroll
                 for (int k = 0; k < 4; k++) full[k] += contrib[k];
@@ -570,7 +608,8 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     }
 
     const float inv_taken = clm_div(1.0f, (float)taken);                  /* :846 */
-    const float ed[4] = {eye_diffuse.x, eye_diffuse.y, eye_diffuse.z, eye_diffuse.w};
+    const float4 ed4 = parked ? park_load(park + 2) : eye_diffuse;
+    const float ed[4] = {ed4.x, ed4.y, ed4.z, ed4.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float c = K.light_emissive[k] * full[k] * inv_taken;
@@ -1265,6 +1304,7 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
     if (MODE == bdpt::MODE_LDS || MODE == bdpt::MODE_LDS2) {
         lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2);
         if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
+        lds += (size_t)BDPT_BLOCK * BDPT_PARK_F4 * sizeof(float4);        /* the lanes' parked eye vertices, behind the scene */
         if (MODE == bdpt::MODE_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return hipErrorInvalidValue;
     }
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;

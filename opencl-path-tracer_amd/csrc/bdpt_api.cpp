@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -172,6 +173,12 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     ctx->rw = width;
     ctx->rh = height;
     bdpt_default_params(&ctx->params);
+    /* BDPT_LAUNCH_CHUNKS in the environment: the initial bdpt_set_launch_chunks of every context (to run an existing
+     * program or test suite with sliced launches throughout) */
+    if (const char *env = std::getenv("BDPT_LAUNCH_CHUNKS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 0 && v <= 4096) ctx->launch_chunks = (int)v;
+    }
     const size_t npix = (size_t)width * height;
     auto bail = [&](hipError_t err, const char *what) {
         std::string msg = std::string("bdpt_create: ") + what + ": " + hipGetErrorString(err);

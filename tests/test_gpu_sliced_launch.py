@@ -116,6 +116,29 @@ def test_runs_of_a_tile_on_different_dies_at_full_occupancy(bdpt, mode):
         _same(_render(bdpt, scene, p, chunks, (48,), size=size), whole, "%s, %d runs" % (mode, chunks))
 
 
+def test_benchmark_sized_launch_sliced_automatically(bdpt):
+    """The headline configuration as bench.py runs it: 1920x1080, 1024 samples per pixel, STRIDED + SUM, adaptive
+    order, automatic slicing (16 runs per tile) -- every bit of the image as from the unsliced launch."""
+    scene = bdpt.Scene.cornell()
+    p = bdpt.default_params(aov_enable=0, **MODES["strided_sum_adaptive"])
+    size = (1920, 1080)
+    with bdpt.Context(*size) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(size[0], size[1], 0x5EED))
+        ctx.set_camera(scene.camera)
+        ctx.render(1024)
+        assert ctx.last_launch_chunks() == 16 and ctx.last_launch_variant() == bdpt.KERNEL_LDS2
+        sliced = ctx.read_accum()
+        ctx.set_launch_chunks(1)
+        ctx.num_samples = 0
+        ctx.render(1024)
+        assert ctx.last_launch_chunks() == 1
+        whole = ctx.read_accum()
+    assert sliced.tobytes() == whole.tobytes()
+    assert np.isfinite(whole).all() and whole[..., :3].max() > 0
+
+
 def test_launch_chunks_argument_is_checked(bdpt):
     with bdpt.Context(16, 8) as ctx:
         with pytest.raises(bdpt.BdptError):

@@ -116,6 +116,19 @@ def test_runs_of_a_tile_on_different_dies_at_full_occupancy(bdpt, mode):
         _same(_render(bdpt, scene, p, chunks, (48,), size=size), whole, "%s, %d runs" % (mode, chunks))
 
 
+@pytest.mark.parametrize("size", [(152, 72), (328, 200), (776, 424)])
+def test_runs_of_a_tile_on_different_dies_with_all_state_cache_resident(bdpt, size):
+    """Frames of 90, 525 and 2 597 tiles (not multiples of the eight dies, so a tile's runs move from die to die)
+    whose whole pixel state fits the second-level caches: a stale cached copy of state that another die has since
+    rewritten would survive here.  STREAM mode with parity buffers hands over the 4-byte arrays too, whose cache
+    lines hold pixels of several tiles.  Two launches of 40 one-sample runs."""
+    scene = bdpt.Scene.cornell()
+    for mode, aov in (("stream_mean", 1), ("strided_sum_adaptive", 0)):
+        p = bdpt.default_params(kernel_variant=5, aov_enable=aov, **MODES[mode])
+        whole = _render(bdpt, scene, p, 1, (40, 40), size=size)
+        _same(_render(bdpt, scene, p, 40, (40, 40), size=size), whole, "%s %dx%d" % (mode, size[0], size[1]))
+
+
 def test_benchmark_sized_launch_sliced_automatically(bdpt):
     """The headline configuration as bench.py runs it: 1920x1080, 1024 samples per pixel, STRIDED + SUM, adaptive
     order, automatic slicing (16 runs per tile) -- every bit of the image as from the unsliced launch."""

@@ -123,6 +123,8 @@ public:
     bool saveCheckpoint(const std::string &path);
     bool loadCheckpoint(const std::string &path, std::string *err = nullptr);
     float lastLaunchMs();
+    /* runs per tile of a render call (bdpt_set_launch_chunks): 0 chosen per launch, 1 unsliced; every device of a group */
+    void setLaunchChunks(int chunks);
     bdpt_ctx *ctx() { return c; }
     bdpt_group *group() { return g; }
     int numDevices() const;

@@ -9,7 +9,7 @@
  *             [--obj model.obj [--obj-surface I] [--obj-scale S] [--obj-translate X,Y,Z]]
  *             [--width W] [--height H] [--frames F] [--spp S] [--orbit-frames K]
  *             [--seed G] [--device D | --devices D0,D1,... [--combine auto|rccl|copy]]
- *             [--out image.pfm|.ppm|.png [--gamma G]] [--quiet]
+ *             [--out image.pfm|.ppm|.png [--gamma G]] [--quiet] [--launch-chunks C]
  *             [--resume state.ckpt] [--checkpoint state.ckpt]
  */
 #include <chrono>
@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     int frames = 64, spp = 1, orbit_frames = 0, n_soup = 100000, device = 0;
     uint32_t seed = 0x5EEDu;
     bool quiet = false;
+    int launch_chunks = 0;
     std::vector<int> devices;                       /* --devices: several GPUs, each frame's samples dealt to them */
     int combine = BDPT_COMBINE_AUTO;
     for (int i = 1; i < argc; i++) {
@@ -80,6 +81,7 @@ int main(int argc, char **argv)
                 return EXIT_FAILURE;
             }
         }
+        else if (!std::strcmp(argv[i], "--launch-chunks")) launch_chunks = std::atoi(next("--launch-chunks"));
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else { std::fprintf(stderr, "ERROR: unknown argument %s\n", argv[i]); return EXIT_FAILURE; }
     }
@@ -113,6 +115,7 @@ int main(int argc, char **argv)
         std::printf("%d devices, partial images combined by %s\n", r.numDevices(),
                     bdpt_group_combine(r.group()) == BDPT_COMBINE_RCCL ? "an RCCL reduce" : "device-to-device copies");
     r.verbose = !quiet;
+    if (launch_chunks != 0) r.setLaunchChunks(launch_chunks);
     r.setScene(scene);
     r.setSeeds(seed);
     if (!resume_path.empty()) {

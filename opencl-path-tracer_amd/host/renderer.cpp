@@ -174,6 +174,12 @@ float Renderer::lastLaunchMs()
     return ms;
 }
 
+void Renderer::setLaunchChunks(int chunks)
+{
+    for (int i = 0; i < numDevices(); i++)
+        check(bdpt_set_launch_chunks(g ? bdpt_group_member(g, i) : c, chunks), "bdpt_set_launch_chunks");
+}
+
 bool write_pfm(const std::string &path, const float *rgba, int width, int height)
 {
     FILE *f = std::fopen(path.c_str(), "wb");

@@ -225,7 +225,7 @@ def main():
             "rng_mode": "strided", "accumulate": "sum", "sample_order": {"auto": "adaptive (roulette classes for pixels whose first eye ray reaches a surface)", "index": "index",
                              "class": "roulette class", "adaptive": "adaptive"}[args.order],
             "kernel_variant": variant_name,
-            "launch": "%d runs per 16x8-pixel tile, each a workgroup of its own (bdpt_set_launch_chunks: automatic)" % ctx.last_launch_chunks(),
+            "launch": "%d runs per workgroup tile (8x8 pixels), each a workgroup of its own (bdpt_set_launch_chunks: automatic)" % ctx.last_launch_chunks(),
             "split": "samples per pixel" if world > 1 else "none",
             "combine": ("%s reduce(sum) of %dx%dx4 f32 to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (host tensors; rehearsal)", W, H)) if world > 1 else "none",
         },

@@ -232,7 +232,7 @@ int bdpt_set_sample_offset(bdpt_ctx *ctx, int first_sample);
  * rays that leave the scene end a path after one ray (kernel0.cl:652-656), so contiguous bands of a frame
  * cost very different amounts; tiles dealt round-robin even that out.  stride 1, phase 0: the whole region. */
 int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, int phase);
-/* How a render call of many samples is run: as `chunks` runs of spp/chunks samples per 16x8-pixel tile, each run
+/* How a render call of many samples is run: as `chunks` runs of spp/chunks samples per workgroup tile (8x8 or 16x8 pixels), each run
  * a workgroup of its own that picks up the tile's pixel state where the run before left it, so that the launch
  * does not end with the GPU draining behind a few long workgroups.  The result is bit-identical for any value.
  * 0 (the default): chosen per launch (up to 16 runs of at least 32 samples; one sample per run for scenes of many

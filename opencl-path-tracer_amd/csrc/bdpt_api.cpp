@@ -197,7 +197,7 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if ((e = hipMalloc((void **)&ctx->d_counters, BDPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counters");
     if ((e = hipMemset(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset counters");
     /* room for the tiles of the whole frame plus one row and one column of split tiles that stick out of it */
-    ctx->slice_tiles = ((width + 15) / 16 + 64) * ((height + 7) / 8 + 64);
+    ctx->slice_tiles = ((width + 7) / 8 + 64) * ((height + 7) / 8 + 64);           /* tiles of 8x8 pixels at the smallest */
     const size_t slice_bytes = (size_t)(4 + ctx->slice_tiles) * sizeof(uint32_t) + 256;   /* header of 4 words; padded for the launcher's rounded clear */
     if ((e = hipMalloc((void **)&ctx->d_slice_sync, slice_bytes)) != hipSuccess) return bail(e, "hipMalloc slice words");
     if ((e = hipMemset(ctx->d_slice_sync, 0, slice_bytes)) != hipSuccess) return bail(e, "hipMemset slice words");
@@ -709,6 +709,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.n_chunks = 1;
     K.chunk_spp = spp;
     K.wg_x = 0;
+    K.block = 0;
     K.width = ctx->width; K.height = ctx->height;
     K.rx0 = ctx->rx0; K.ry0 = ctx->ry0; K.rw = ctx->rw; K.rh = ctx->rh;
     K.tile_stride = ctx->tile_stride; K.tile_phase = ctx->tile_phase;

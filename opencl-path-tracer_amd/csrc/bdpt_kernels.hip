@@ -8,7 +8,7 @@
  * accumulator is read and written once per launch (one float4 per pixel).
  *
  * Lane -> pixel: a wavefront covers an 8x8 pixel tile (lane & 7 = x, lane >> 3
- * = y), a workgroup BDPT_BLOCK / 64 tiles side by side, so that
+ * = y), a workgroup one such tile or two side by side (bdpt_kargs.block), so that
  * the eye rays of a wavefront stay coherent and silhouette edges cut through as
  * few wavefronts as possible.
  *
@@ -18,10 +18,11 @@
 #include "bdpt_device.h"
 #include "bdpt_kernels.h"
 
-/* Workgroup: two wavefronts, i.e. two 8x8 pixel tiles side by side (measured against one and four:
- * 245.9 / 248.2 / 249.9 ms per 1024-spp Cornell launch for 128 / 64 / 256 threads). */
-#define BDPT_BLOCK 128
-#define BDPT_BLOCK_W (BDPT_BLOCK / 8)
+/* Workgroup: one wavefront (one 8x8 pixel tile) or two (two tiles side by side), chosen per launch (launch_block).
+ * One is faster where it fits (1080p Cornell box, 1024 spp: 129.9 against 133.0 ms; 100 000 triangles 915 against
+ * 944 ms per 4 samples): a workgroup's slot is free as soon as its wavefront ends, and the barriers of a sliced launch
+ * are no-ops.  The LDS kernels copy the scene once per workgroup, so larger scenes take two wavefronts per copy. */
+#define BDPT_BLOCK_MAX 128
 
 namespace bdpt {
 
@@ -163,14 +164,14 @@ BDPT_DEV void pixel_state_store(const bdpt_kargs &K, const Slice &sl, size_t pix
     }
 }
 
-/* Pixel of this lane in tile `tile`.  Whole region: the tiles are 16x8 pixels, wg_x per row.  Interleaved tile
+/* Pixel of this lane in tile `tile`.  Whole region: the tiles are a workgroup's pixels (8x8 or 16x8), wg_x per row.  Interleaved tile
  * split: the tiles enumerate, split tile after split tile, the workgroups of the split tiles this launch owns. */
 BDPT_DEV void lane_pixel(const bdpt_kargs &K, int tile, int &x, int &y)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int bx, by, ox = K.rx0, oy = K.ry0;
     if (K.tile_stride > 1) {
-        const int bw = K.tile_w / BDPT_BLOCK_W, per_tile = bw * (K.tile_h / 8);
+        const int bw = K.tile_w / (K.block >> 3), per_tile = bw * (K.tile_h / 8);
         const int owned = tile / per_tile, local = tile % per_tile;
         const int t = K.tile_phase + owned * K.tile_stride;
         ox += (t % K.tiles_x) * K.tile_w;
@@ -184,7 +185,7 @@ BDPT_DEV void lane_pixel(const bdpt_kargs &K, int tile, int &x, int &y)
         bx = tile % K.wg_x;
         by = tile / K.wg_x;
     }
-    x = ox + bx * BDPT_BLOCK_W + wv * 8 + (lane & 7);
+    x = ox + bx * (K.block >> 3) + wv * 8 + (lane & 7);
     y = oy + by * 8 + (lane >> 3);
 }
 
@@ -629,7 +630,7 @@ template <bool AOV, bool COUNT, int MODE, bool ALT>
 #ifndef BDPT_LDS2_WAVES
 #define BDPT_LDS2_WAVES 6
 #endif
-__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
+__global__ __launch_bounds__(BDPT_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
@@ -1022,11 +1023,10 @@ BDPT_DEV bool sample_tiled(const bdpt_kargs &K, float4 *wave_lds, bool live, flo
 #define BDPT_TILED_WAVES 5
 #endif
 template <bool AOV, bool COUNT, bool ALT>
-__global__ __launch_bounds__(BDPT_BLOCK) __attribute__((amdgpu_waves_per_eu(BDPT_TILED_WAVES, BDPT_TILED_WAVES)))
+__global__ __launch_bounds__(BDPT_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(BDPT_TILED_WAVES, BDPT_TILED_WAVES)))
 void bdpt_tiled_kernel(const bdpt_kargs K)
 {
-    __shared__ float4 tiles[BDPT_BLOCK / 64][2 * BDPT_TILE_F4];
-    float4 *wave_lds = tiles[threadIdx.x >> 6];
+    float4 *wave_lds = bdpt_lds + (threadIdx.x >> 6) * (2 * BDPT_TILE_F4);   /* dynamic LDS: two tile buffers per wavefront */
     const Slice sl = slice_begin(K);
     int x, y;
     lane_pixel(K, sl.tile, x, y);
@@ -1121,7 +1121,7 @@ void bdpt_tiled_kernel(const bdpt_kargs K)
 /* ------------------------------------------------------------------------- */
 
 template <bool AOV>
-__global__ __launch_bounds__(BDPT_BLOCK) void bdpt_path_trace_kernel(const bdpt_kargs K)
+__global__ __launch_bounds__(BDPT_BLOCK_MAX) void bdpt_path_trace_kernel(const bdpt_kargs K)
 {
     int x, y;
     lane_pixel(K, (int)(blockIdx.y * gridDim.x + blockIdx.x), x, y);
@@ -1269,10 +1269,11 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 /* grid of a per-pixel launch: see lane_pixel */
 static dim3 pixel_grid(const bdpt_kargs &K)
 {
-    if (K.tile_stride <= 1) return dim3((K.rw + BDPT_BLOCK_W - 1) / BDPT_BLOCK_W, (K.rh + 7) / 8);
+    const int block_w = K.block >> 3;
+    if (K.tile_stride <= 1) return dim3((K.rw + block_w - 1) / block_w, (K.rh + 7) / 8);
     const int tiles_y = (K.rh + K.tile_h - 1) / K.tile_h, n_tiles = K.tiles_x * tiles_y;
     const int owned = n_tiles > K.tile_phase ? (n_tiles - K.tile_phase + K.tile_stride - 1) / K.tile_stride : 0;
-    return dim3((unsigned)owned * (K.tile_w / BDPT_BLOCK_W) * (K.tile_h / 8), 1);
+    return dim3((unsigned)owned * (K.tile_w / block_w) * (K.tile_h / 8), 1);
 }
 
 /* Grid of a launch that may be sliced.  On entry K.n_tiles is the number of tiles K.slice_sync has room for; a
@@ -1291,22 +1292,32 @@ static hipError_t sliced_grid(bdpt_kargs &K, dim3 &grid, hipStream_t stream)
     return hipMemsetAsync(K.slice_sync, 0, bytes < 256 ? 256 : bytes, stream);
 }
 
+/* Threads per workgroup of a launch whose workgroups need `per_wave` bytes of LDS for each wavefront and `shared`
+ * bytes once: one wavefront where 24 such workgroups (six per SIMD) fit the 160 KB of a compute unit, else two. */
+static int launch_block(size_t shared, size_t per_wave)
+{
+    return 24 * (shared + per_wave) <= 160 * 1024 ? 64 : BDPT_BLOCK_MAX;
+}
+
 template <int MODE>
 static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    dim3 grid;
-    const dim3 block(BDPT_BLOCK);
-    const hipError_t e = sliced_grid(K, grid, stream);
-    if (e != hipSuccess) return e;
-    if (grid.x == 0) return hipSuccess;                  /* this share owns no tile of the region */
     size_t lds = 0;
+    K.block = 64;
     if (MODE == bdpt::MODE_LDS || MODE == bdpt::MODE_LDS2) {
         lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2);
         if (lds > BDPT_LDS_SCENE_MAX) return hipErrorInvalidValue;
-        lds += (size_t)BDPT_BLOCK * BDPT_PARK_F4 * sizeof(float4);        /* the lanes' parked eye vertices, behind the scene */
+        const size_t park = (size_t)64 * BDPT_PARK_F4 * sizeof(float4);   /* the lanes' parked eye vertices, behind the scene */
+        K.block = launch_block(lds, park);
+        lds += park * (K.block / 64);
         if (MODE == bdpt::MODE_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return hipErrorInvalidValue;
     }
+    dim3 grid;
+    const dim3 block(K.block);
+    const hipError_t e = sliced_grid(K, grid, stream);
+    if (e != hipSuccess) return e;
+    if (grid.x == 0) return hipSuccess;                  /* this share owns no tile of the region */
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
 #define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_direct_kernel<A, C, MODE, X>), grid, block, lds, stream, K)
     if (alt) {
@@ -1350,13 +1361,16 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K_in, bool aov, bool count, hipSt
 {
     bdpt_kargs K = K_in;
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    const size_t tile_bytes = (size_t)2 * BDPT_TILE_F4 * sizeof(float4);  /* per wavefront */
+    K.block = launch_block(0, tile_bytes);
     dim3 grid;
-    const dim3 block(BDPT_BLOCK);
+    const dim3 block(K.block);
     const hipError_t e = sliced_grid(K, grid, stream);
     if (e != hipSuccess) return e;
     if (grid.x == 0) return hipSuccess;
     const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
-#define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, 0, stream, K)
+    const size_t lds = tile_bytes * (K.block / 64);
+#define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_tiled_kernel<A, C, X>), grid, block, lds, stream, K)
     if (alt) {
         if (aov && count) BDPT_LAUNCH(true, true, true);
         else if (aov) BDPT_LAUNCH(true, false, true);
@@ -1386,10 +1400,12 @@ hipError_t bdpt_launch_scale(float4 *dst, size_t n, float factor, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream)
+hipError_t bdpt_launch_path_trace(const bdpt_kargs &K_in, bool aov, hipStream_t stream)
 {
+    bdpt_kargs K = K_in;
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    const dim3 grid = pixel_grid(K), block(BDPT_BLOCK);
+    K.block = 64;
+    const dim3 grid = pixel_grid(K), block(K.block);
     if (grid.x == 0) return hipSuccess;
     if (K.n_chunks > 1) return hipErrorInvalidValue;    /* this kernel has no sliced form */
     if (aov) hipLaunchKernelGGL(bdpt::bdpt_path_trace_kernel<true>, grid, block, 0, stream, K);

@@ -92,7 +92,7 @@ struct bdpt_kargs {
     int rx0, ry0, rw, rh;       /* region rendered by this launch */
     /* Interleaved tile split: the region is cut into tiles of tile_w x tile_h pixels, numbered row by row
      * (tiles_x per row), and this launch renders the tiles whose number is tile_phase modulo tile_stride.
-     * tile_stride <= 1: the whole region.  tile_w is a multiple of the workgroup's 16 pixels, tile_h of 8. */
+     * tile_stride <= 1: the whole region.  tile_w is a multiple of 16 (a workgroup is 8 or 16 pixels wide), tile_h of 8. */
     int tile_w, tile_h, tiles_x, tile_stride, tile_phase;
     /* Sliced launch (see slice_begin in bdpt_kernels.hip): n_chunks > 1 starts n_chunks workgroups per tile, each
      * running chunk_spp samples.  slice_sync[0] is the ticket counter, slice_sync[1 + t] the number of runs of tile
@@ -101,6 +101,7 @@ struct bdpt_kargs {
     uint32_t *slice_sync;
     uint4 *slice_cursor;
     int n_chunks, chunk_spp, n_tiles, wg_x;
+    int block;                  /* threads per workgroup, 64 or 128: one 8x8-pixel tile per wavefront, side by side (set by the launcher) */
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;
     uint32_t first_sample;      /* STRIDED: sample_offset + num_samples */

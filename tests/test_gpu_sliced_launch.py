@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-W, H = 88, 52                      # ragged against the 16x8 workgroup tiles
+W, H = 88, 52                      # ragged against the workgroup tiles
 AOVS = ("AOV_EYE_HIT", "AOV_HIT_HASH", "AOV_RADIANCE", "AOV_RNG_DRAWS", "AOV_RAYS")
 
 MODES = {

@@ -70,6 +70,8 @@ struct bdpt_ctx {
     int slice_tiles = 0;               /* tiles d_slice_sync has room for */
     int launch_chunks = 0;             /* bdpt_set_launch_chunks: 0 = chosen per launch */
     bool sliced_unchecked = false;     /* a sliced launch was issued and its give-up mark has not been read yet */
+    double ms_per_pixel_sample = 0.0;  /* measured on an earlier launch of this scene and these parameters; 0 = not yet */
+    double last_launch_work = 0.0;     /* pixels x samples of the last launch, until its time has been read */
 
     std::string err;
 };
@@ -81,6 +83,8 @@ struct bdpt_ctx {
 #ifndef BDPT_AUTO_CHUNK_MIN_SPP
 #define BDPT_AUTO_CHUNK_MIN_SPP 32
 #endif
+/* what one more run costs per pixel (its state re-read and re-written): 1.06 ms per run of a 3840x2160 frame */
+#define BDPT_RUN_COST_MS_PER_PIXEL 1.28e-7
 
 static_assert(BDPT_QUERY_NOALLOC_MAX_RAYS == BDPT_QUERY_STATIC_MAX, "the documented limit is the size of the staging array");
 
@@ -294,6 +298,7 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->params = *p;
+    ctx->ms_per_pixel_sample = ctx->last_launch_work = 0.0;               /* other parameters, other cost per sample */
     if (p->aov_enable) return ensure_aovs(ctx);
     return BDPT_OK;
 }
@@ -553,6 +558,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     ctx->n_planes = n_planes;
     ctx->n_triangles = n_triangles;
     ctx->have_scene = true;
+    ctx->ms_per_pixel_sample = ctx->last_launch_work = 0.0;
     ctx->num_samples = 0;
     return reset_aovs(ctx);
 }
@@ -615,6 +621,7 @@ int bdpt_set_region(bdpt_ctx *ctx, int x0, int y0, int w, int h)
     if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > ctx->width || y0 + h > ctx->height)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_region: rectangle outside the image");
     ctx->rx0 = x0; ctx->ry0 = y0; ctx->rw = w; ctx->rh = h;
+    ctx->ms_per_pixel_sample = ctx->last_launch_work = 0.0;               /* another part of the frame, another mix of paths */
     return BDPT_OK;
 }
 
@@ -780,6 +787,19 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     int rc = fill_kargs(ctx, spp, K);
     if (rc != BDPT_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    /* how long a sample of this scene takes, from the last launch if it has ended (no waiting; a stream under
+     * capture is left alone) */
+    if (ctx->have_launch && ctx->last_launch_work > 0.0) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &capturing) != hipSuccess) (void)hipGetLastError();
+        if (capturing == hipStreamCaptureStatusNone) {
+            float ms = 0.0f;
+            if (hipEventQuery(ctx->ev_end) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f) {
+                ctx->ms_per_pixel_sample = ms / ctx->last_launch_work;
+                ctx->last_launch_work = 0.0;
+            } else (void)hipGetLastError();              /* not ready is not an error */
+        }
+    }
     const bool aov = ctx->params.aov_enable != 0;
     if (aov && (rc = ensure_aovs(ctx)) != BDPT_OK) return rc;
     int variant = ctx->params.kernel_variant;
@@ -792,12 +812,20 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
                   : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
     /* Sliced launch (slice_begin in bdpt_kernels.hip): runs short enough that the launch does not end with a long
      * drain, long enough that the per-run reload of the pixel state does not show (1080p Cornell box: 64 samples
-     * 12.9 -> 12.0 ms as 4 runs, 256 samples 47.5 -> 42.2 ms as 16, 1024 samples 175 -> 158 ms as 16; 8 samples
-     * lose 4 % as 2 runs).  The many-triangle kernel spends so long on a sample that one sample is a run already
+     * 10.4 -> 9.8 ms as 8 runs, 256 samples 47.5 -> 42.2 ms as 16, 1024 samples 175 -> 158 ms as 16, no gain from
+     * 32 or 64; 8 samples lose 4 % as 2 runs).  The many-triangle kernel spends so long on a sample that one sample is a run already
      * (100 000 triangles, 16 samples: 3.59 -> 3.27 s as 8 or 16 runs). */
     if (ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE) {
         int chunks = ctx->launch_chunks;
-        if (chunks == 0) chunks = variant == BDPT_KERNEL_TILED ? BDPT_AUTO_CHUNKS : std::min(BDPT_AUTO_CHUNKS, spp / BDPT_AUTO_CHUNK_MIN_SPP);
+        if (chunks == 0) {
+            /* a run should last a few times what it costs to start; how long a sample takes is known from the last
+             * launch of this scene (the Cornell box: 6e-8 ms per pixel, runs of 7 samples; six spheres under an open
+             * sky: 1.2e-8, runs of 34), else assumed short */
+            int min_spp = variant == BDPT_KERNEL_TILED ? 1 : BDPT_AUTO_CHUNK_MIN_SPP;
+            if (ctx->ms_per_pixel_sample > 0.0)
+                min_spp = (int)std::min(64.0, std::max(1.0, std::ceil(3.0 * BDPT_RUN_COST_MS_PER_PIXEL / ctx->ms_per_pixel_sample)));
+            chunks = std::min(BDPT_AUTO_CHUNKS, spp / min_spp);
+        }
         chunks = std::max(1, std::min(chunks, spp));
         K.chunk_spp = (spp + chunks - 1) / chunks;
         K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
@@ -814,6 +842,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;
+    ctx->last_launch_work = (double)K.rw * K.rh / std::max(1, K.tile_stride) * spp;
     ctx->last_variant = variant;
     ctx->last_chunks = K.n_chunks;
     ctx->num_samples += spp;                                              /* main.cpp:131 */

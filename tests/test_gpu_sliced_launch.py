@@ -95,7 +95,8 @@ def test_sliced_launch_matches_the_oracle(bdpt, oracle, variant):
 
 
 def test_automatic_slicing_leaves_results_alone_and_short_launches_whole(bdpt):
-    """chunks = 0: launches of at least 64 samples are sliced by the small-scene kernels, every launch of more than one
+    """chunks = 0: launches of at least 64 samples are sliced by the small-scene kernels (of fewer once the context
+    knows how long a sample takes), every launch of more than one
     sample by the many-triangle kernel; results as with one run."""
     for variant, spp in ((5, 70), (4, 9)):
         scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()

@@ -444,30 +444,24 @@ BDPT_DEV uint32_t roulette_stops(uint32_t x, uint32_t step, uint32_t fate_above)
 /* Number of light-subpath vertices roulette allows a sample; same cost for every lane.  A sample
  * draws 8 numbers before its first roulette draw (1 discarded, 2 pixel jitter, 2 light point, 3 first
  * cone sample) and 3 between one roulette draw and the next, so roulette draw k is the generator's
- * output number 9+4k: the start state times 48271^(9+4k).  Straight-line code for the subpath lengths a
- * STRIDED launch can have (at most seven vertices: the draws of a sample must fit its stride). */
+ * output number 9+4k: the start state times 48271^(9+4k).
+ * N > 0: straight-line code that looks at N draws, for max_l <= N + 1 (draws past max_l - 1 set bits
+ * above the one that caps the walk and are never seen); N = 0: a loop, any max_l. */
+template <int N>
 BDPT_DEV int roulette_class(const bdpt_kargs &K, uint32_t start_state)
 {
     const bool five = sampler_draws_four(K.sampler);           /* one more draw per vertex: 10 + 5k */
     const uint32_t step = five ? lcg_pow(5) : lcg_pow(4);
     const uint32_t x = start_state * (five ? lcg_pow(10) : lcg_pow(9));
-    uint32_t stops;
-    switch (K.max_l) {                                         /* wave-uniform */
-    case 1: stops = 0u; break;
-    case 2: stops = roulette_stops<1>(x, step, K.fate_above); break;
-    case 3: stops = roulette_stops<2>(x, step, K.fate_above); break;
-    case 4: stops = roulette_stops<3>(x, step, K.fate_above); break;
-    case 5: stops = roulette_stops<4>(x, step, K.fate_above); break;
-    case 6: stops = roulette_stops<5>(x, step, K.fate_above); break;
-    case 7: stops = roulette_stops<6>(x, step, K.fate_above); break;
-    default: {
-        stops = 0u;
+    uint32_t stops = 0u;
+    if (N > 0) {
+        stops = roulette_stops<N>(x, step, K.fate_above);
+    } else {
         uint32_t y = x;
         for (int k = 0; k + 1 < K.max_l && k < 31; k++) {
             stops |= y > K.fate_above ? (1u << k) : 0u;
             y *= step;
         }
-    }
     }
     if (K.max_l <= 32) stops |= 1u << (K.max_l - 1);           /* the walk never has more than max_l vertices */
     return stops ? __builtin_ctz(stops) + 1 : K.max_l;
@@ -509,14 +503,45 @@ BDPT_DEV constexpr StrideInvPow make_stride_inv_pow()
 static __device__ const StrideInvPow kStrideInvPow = make_stride_inv_pow();
 
 /*
+ * The reordered case of cursor_next.  A lane finds its next sample of the current class by classifying
+ * sample indices ahead of the last one it traced.  The lanes of a wavefront do this together, one index
+ * per lane per round, until every lane has a sample to trace; a lane that already has one keeps
+ * classifying (up to 32 indices past its oldest untraced sample) and remembers what it finds in
+ * `pending`, so that it seldom is the lane the others wait for.  A round is selects and two votes;
+ * what depends on max_l alone is decided outside the loop (N as in roulette_class).
+ */
+template <int N>
+BDPT_DEV bool cursor_rounds(SampleCursor &c, const bdpt_kargs &K, const uint32_t *seed_w, uint32_t &start)
+{
+    for (;;) {
+        const bool starved = c.pending == 0u && c.cls >= 1;
+        if (__builtin_amdgcn_ballot_w64(starved) == 0) break;
+        const bool next_class = starved && c.head >= K.spp;  /* no more samples of this class */
+        if (__builtin_amdgcn_ballot_w64(next_class) != 0) {
+            asm volatile("");                                /* a real branch: a handful of times per launch */
+            if (next_class) {
+                c.cls--;
+                c.head = 0;
+                c.st_head = cursor_first_state(K, *seed_w);
+            }
+            continue;                                        /* the lane may have run out of classes */
+        }
+        const bool advance = c.cls >= 1 && c.head < K.spp && (c.pending >> 31) == 0u;
+        const uint32_t found = roulette_class<N>(K, c.st_head) == c.cls ? 1u : 0u;
+        c.pending = advance ? ((c.pending << 1) | found) : c.pending;
+        c.head += advance ? 1 : 0;
+        c.st_head = advance ? c.st_head * kSampleStride : c.st_head;
+    }
+    if (c.cls < 1) return false;
+    const int i = 31 - __builtin_clz(c.pending);             /* oldest pending sample: index head-1-i */
+    c.pending &= ~(1u << i);
+    start = c.st_head * kStrideInvPow.v[i + 1];              /* back from sample head to sample head-1-i */
+    return true;
+}
+
+/*
  * false when the launch has no more samples for this pixel; otherwise start = start state (STRIDED).
  * seed_w = the pixel's seed word, wanted again when a lane restarts at sample 0 for the next class.
- *
- * In a reordered launch a lane finds its next sample of the current class by classifying sample
- * indices ahead of the last one it traced.  The lanes of a wavefront do this together, one index per
- * lane per round, until every lane has a sample to trace; a lane that already has one keeps
- * classifying (up to 32 indices past its oldest untraced sample) and remembers what it finds in
- * `pending`, so that it seldom is the lane the others wait for.
  */
 BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *seed_w, uint32_t &start)
 {
@@ -527,30 +552,9 @@ BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *
         c.head++;
         return true;
     }
-    for (;;) {                                               /* one round: selects, no per-lane branches */
-        const bool starved = c.pending == 0u;
-        const bool next_class = starved && c.head >= K.spp && c.cls >= 1;   /* no more samples of this class */
-        if (__builtin_amdgcn_ballot_w64(next_class) != 0) {
-            asm volatile("");                                /* a real branch: a handful of times per launch */
-            if (next_class) {
-                c.cls--;
-                c.head = 0;
-                c.st_head = cursor_first_state(K, *seed_w);
-            }
-        }
-        const bool done = c.cls < 1;
-        if (__builtin_amdgcn_ballot_w64(starved && !done) == 0) break;
-        const bool advance = !done && c.head < K.spp && (c.pending >> 31) == 0u;
-        const uint32_t found = roulette_class(K, c.st_head) == c.cls ? 1u : 0u;
-        c.pending = advance ? ((c.pending << 1) | found) : c.pending;
-        c.head += advance ? 1 : 0;
-        c.st_head = advance ? c.st_head * kSampleStride : c.st_head;
-    }
-    if (c.cls < 1) return false;
-    const int i = 31 - __builtin_clz(c.pending);             /* oldest pending sample: index head-1-i */
-    c.pending &= ~(1u << i);
-    start = c.st_head * kStrideInvPow.v[i + 1];              /* back from sample head to sample head-1-i */
-    return true;
+    if (K.max_l <= 5) return cursor_rounds<4>(c, K, seed_w, start);
+    if (K.max_l <= 7) return cursor_rounds<6>(c, K, seed_w, start);
+    return cursor_rounds<0>(c, K, seed_w, start);
 }
 
 /* one link of the per-pixel hit-id chain (the additive constant keeps a run of

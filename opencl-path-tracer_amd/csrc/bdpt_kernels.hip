@@ -379,10 +379,25 @@ BDPT_DEV Hit closest_hit_lds(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int ot
  * bit-identical with the other variants.                                       */
 /* ------------------------------------------------------------------------- */
 
+/* -DBDPT_PHASE_CLOCKS: an instrumented build for tools/phase_clocks.py.  Every wavefront adds up the clock ticks it
+ * spends in each part of the search (sphere and plane walk, stage 1, stage 2, winner's record) and in the samples as a
+ * whole; bdpt_phase_clocks() reads the sums.  Slower than the plain build, same results. */
+#ifdef BDPT_PHASE_CLOCKS
+__device__ unsigned long long bdpt_phase_clocks_dev[12];
+#define BDPT_PHASE_BEGIN unsigned long long phase_t = clock64()
+#define BDPT_PHASE_END(i) do { if (clk) { const unsigned long long now = clock64(); clk[i] += now - phase_t; phase_t = now; } } while (0)
+#define BDPT_PHASE_RESUME phase_t = clock64()
+#else
+#define BDPT_PHASE_BEGIN
+#define BDPT_PHASE_END(i)
+#define BDPT_PHASE_RESUME
+#endif
+
 template <bool COUNT>
 BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx,
-                              unsigned long long *n_cull, unsigned long long *n_exact)
+                              unsigned long long *n_cull, unsigned long long *n_exact, unsigned long long *clk = nullptr)
 {
+    BDPT_PHASE_BEGIN;
     Best b;
     best_init(b);                                                         /* kernel0.cl:374, :384-385 */
     const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
@@ -397,6 +412,7 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
         const float4 q0 = bdpt_lds[L.pln + i * BDPT_PLN_F4], q1 = bdpt_lds[L.pln + i * BDPT_PLN_F4 + 1];
         if (i != skip_p) test_plane(b, q0, q1, i, o, d);
     }
+    BDPT_PHASE_END(1);
     /* (C + |o|_1) |d|_inf, doubled: the ray's part of the margin */
     const float ray_margin = 2.0f * (S.cull_c + fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) * fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
     for (int base = 0; base < S.n_triangles; base += 32) {
@@ -450,6 +466,7 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             mask |= kept(h, c1, c2, c3.x) ? __float_as_uint(c3.y) : 0u;
         }
         if (COUNT) *n_cull += (unsigned long long)cnt;
+        BDPT_PHASE_END(2);
         if (skip_t >= base && skip_t < base + 32) mask &= ~(1u << (skip_t - base));                   /* :436 */
         while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0) {            /* stage 2 */
             const bool wanted = mask != 0u;
@@ -462,8 +479,11 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             test_triangle_flat(b, q0, q1, q2, q3, q4, e2z, i, wanted, o, d);
             if (COUNT && wanted) ++*n_exact;
         }
+        BDPT_PHASE_END(3);
     }
-    return finish_hit_lds<true>(S, b, d);
+    const Hit found = finish_hit_lds<true>(S, b, d);
+    BDPT_PHASE_END(4);
+    return found;
 }
 
 enum { MODE_DIRECT = 0, MODE_LDS = 2, MODE_LDS2 = 3 };
@@ -471,6 +491,9 @@ enum { MODE_DIRECT = 0, MODE_LDS = 2, MODE_LDS2 = 3 };
 /* per-lane work counters of a counting launch */
 struct Tally {
     unsigned long long rays, full, early, cull, exact;
+#ifdef BDPT_PHASE_CLOCKS
+    unsigned long long clk[12];
+#endif
 };
 
 /* row `i` of the surface table (2 float4 per surface: colour, emissive) */
@@ -508,6 +531,9 @@ BDPT_DEV float4 park_load(const volatile float4 *p)
 template <int MODE, bool SCATTERED, bool COUNT>
 BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, int oidx, Tally &T)
 {
+#ifdef BDPT_PHASE_CLOCKS
+    if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact, T.clk);
+#endif
     if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact);
     return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
 }
@@ -523,10 +549,16 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
                             uint32_t &hash, int eye_id[2], float col[4], Tally &T)
 {
     const bdpt_dev_scene &S = K.scene;
+#ifdef BDPT_PHASE_CLOCKS
+    unsigned long long *const clk = T.clk;
+#endif
+    BDPT_PHASE_BEGIN;
     rng_float(w, draws);                                                  /* :592, discarded */
     clm_f3 dir = camera_ray(w, draws, K, xt, yt);
     clm_f3 eye_pos = clm_mad3(0.00001f, dir, f3(K.cam_pos));              /* :632 */
+    BDPT_PHASE_END(5);
     Hit eye = trace_one<MODE, false, COUNT>(S, eye_pos, dir, 4, 0, T);        /* :634 */
+    BDPT_PHASE_RESUME;
     rays++;
     if (AOV) { hash = hash_step(hash, hit_id(eye.type, eye.idx)); eye_id[0] = eye.type; eye_id[1] = eye.idx; }
 
@@ -550,7 +582,9 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
     }
 
     clm_f3 vpos, vn;                                                      /* current light-subpath vertex */
+    BDPT_PHASE_END(5);
     sample_light(w, draws, K, vpos, vn);                                  /* :669 */
+    BDPT_PHASE_END(6);
     int vtype = K.light_origin_type, vidx = K.light_origin_index;
 
     float full[4] = {0.0f, 0.0f, 0.0f, 0.0f};                             /* :689 */
@@ -563,7 +597,9 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
             clm_f3 to = eye.pos;
             if (parked) { const float4 e0 = park_load(park + 0); to = clm_make3(e0.x, e0.y, e0.z); }
             clm_f3 tdir = clm_normalize3(clm_sub3(to, vpos));             /* :699 */
+            BDPT_PHASE_END(7);
             Hit vis = trace_one<MODE, true, COUNT>(S, vpos, tdir, vtype, vidx, T);  /* :705 */
+            BDPT_PHASE_RESUME;
             rays++;
             if (AOV) hash = hash_step(hash, hit_id(vis.type, vis.idx));
             float contrib[4];
@@ -581,6 +617,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         }
         pre *= K.p_con;                                                   /* :745 */
         taken++;                                                          /* :757 */
+        BDPT_PHASE_END(7);
 
         clm_f3 lpos = clm_mad3(0.00001f, vn, vpos);                       /* :761 */
         /* The bounce direction (:767) is used only if roulette (:787) lets the walk go on, and it
@@ -596,7 +633,9 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         clm_f3 ldir = ALT ? sample_bounce_alt(K, w_dir, draws_dir, vn, incoming, lpos)
                           : sample_cone(w_dir, draws_dir, vn, 3.1415f * 0.50f);   /* :767, :486 */
 
+        BDPT_PHASE_END(8);
         Hit nxt = trace_one<MODE, true, COUNT>(S, lpos, ldir, vtype, vidx, T);   /* :793 */
+        BDPT_PHASE_RESUME;
         rays++;
         if (AOV) hash = hash_step(hash, hit_id(nxt.type, nxt.idx));
         if (nxt.type < 0) break;                                          /* :812 */
@@ -606,7 +645,9 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         acc[0] *= nd.x; acc[1] *= nd.y; acc[2] *= nd.z; acc[3] *= nd.w;   /* :827 with :822, :824 */
         if (ALT) incoming = ldir;                                         /* :831 */
         vpos = nxt.pos; vn = nxt.n; vtype = nxt.type; vidx = nxt.idx;     /* :832 */
+        BDPT_PHASE_END(9);
     }
+    BDPT_PHASE_RESUME;
 
     const float inv_taken = clm_div(1.0f, (float)taken);                  /* :846 */
     const float4 ed4 = parked ? park_load(park + 2) : eye_diffuse;
@@ -617,6 +658,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         if (!K.indirect_only) c = c * ed[k];                              /* :844 / :846 */
         col[k] = c;
     }
+    BDPT_PHASE_END(9);
     return false;
 }
 
@@ -658,7 +700,10 @@ BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
 
     uint32_t draws = 0, rays = 0, hash = 0;
     if (AOV) { draws = K.aov_rng_draws[pix]; rays = K.aov_rays[pix]; hash = K.aov_hit_hash[pix]; }
-    Tally T = {0, 0, 0, 0, 0};
+    Tally T = {};
+#ifdef BDPT_PHASE_CLOCKS
+    const unsigned long long pixel_t0 = clock64();
+#endif
     int eye_id[2] = {-1, -1};
     float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -677,12 +722,19 @@ BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
     }
 
     uint32_t start;
+#ifdef BDPT_PHASE_CLOCKS
+    unsigned long long *const clk = T.clk;
+    T.clk[11] = clock64() - pixel_t0;
+#endif
+    BDPT_PHASE_BEGIN;
     for (int s = sl.s0; s < sl.s1 && cursor_next(cur, K, &K.seed_w[pix], start); s++) {   /* s counts the samples taken so far */
+        BDPT_PHASE_END(10);
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;
         const uint32_t w_before = w;
         const uint32_t rays_before = rays;
         const bool early = sample_direct<AOV, MODE, ALT, AOV, COUNT>(K, xt, yt, w, draws, rays, hash, eye_id, col, T);
+        BDPT_PHASE_RESUME;
         if (COUNT) { T.rays += rays - rays_before; if (early) T.early++; else T.full++; }
 
         if (early && K.rng_mode == BDPT_RNG_STREAM) {
@@ -716,6 +768,11 @@ BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
     }
 
     pixel_state_store<AOV>(K, sl, pix, acc, w, cur, eye_id, hash, col, draws, rays);
+#ifdef BDPT_PHASE_CLOCKS
+    T.clk[0] = clock64() - pixel_t0;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)    /* the wavefront's first active lane */
+        for (int i = 0; i < 12; i++) atomicAdd(&bdpt_phase_clocks_dev[i], T.clk[i]);
+#endif
     if (COUNT) {
         atomicAdd(&K.counters[0], T.rays);
         atomicAdd(&K.counters[1], T.full);
@@ -1459,3 +1516,17 @@ hipError_t bdpt_launch_clmath(int op, const double *in, double *out, int n, hipS
     hipLaunchKernelGGL(bdpt::bdpt_clmath_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n);
     return hipGetLastError();
 }
+
+#ifdef BDPT_PHASE_CLOCKS
+/* instrumented builds only: the clock sums of every launch since the last reset (tools/phase_clocks.py) */
+extern "C" int bdpt_phase_clocks(unsigned long long out[12], int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bdpt::bdpt_phase_clocks_dev), 12 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long zero[12] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(bdpt::bdpt_phase_clocks_dev), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

@@ -265,8 +265,9 @@ def main():
             # per cull test: the plane part (19 flops) is shared by the two triangles of a pair; a triangle's own part
             # is 19 flops (two coordinate planes, the third coordinate, minimum, margin, compare), 12.5 for each half
             # of a parallelogram, which shares the coordinate planes as well
-            quads, pairs, singles = ctx.two_stage_record_counts()
-            f_cull = (quads * 44 + pairs * 57 + singles * 38) / max(1, 2 * quads + 2 * pairs + singles)
+            # two opposite walls of a box (four triangles) go through one such test of 42 flops
+            quads, pairs, singles, slabs = ctx.two_stage_record_counts()
+            f_cull = (slabs * 42 + quads * 44 + pairs * 57 + singles * 38) / max(1, 4 * slabs + 2 * quads + 2 * pairs + singles)
         if variant in F_CULL:
             # a cheap conservative test decides most (ray, triangle) pairs; price the tests that were run
             flops = int(rays * (F_SPHERE * n_s + F_PLANE * n_p + F_RAY_FIXED) + n_cull * f_cull + n_exact * F_TRIANGLE + f_paths)

@@ -308,9 +308,10 @@ int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n
 /* BDPT_KERNEL_* that the last launch ran (what AUTO resolved to), 0 before the first launch. */
 int bdpt_last_launch_variant(const bdpt_ctx *ctx);
 /* How the uploaded scene's triangles are grouped for the two-stage kernel's conservative test: out[0] pairs that
- * are the two halves of a parallelogram, out[1] other pairs in one plane, out[2] triangles on their own (all 0 for
- * scenes that kernel does not take).  Diagnostic; no reference counterpart. */
-int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[3]);
+ * are the two halves of a parallelogram, out[1] other pairs in one plane, out[2] triangles on their own, out[3]
+ * pairs of parallelograms that are opposite walls of a box (four triangles each, not counted in out[0]); all 0
+ * for scenes that kernel does not take.  Diagnostic; no reference counterpart. */
+int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[4]);
 /* Device time of the most recent render launch in milliseconds (HIP events on
  * the stream the kernel ran on); waits for that launch. */
 int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms);

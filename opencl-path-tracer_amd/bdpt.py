@@ -431,8 +431,9 @@ class Context:
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
 
     def two_stage_record_counts(self):
-        """(parallelogram pairs, other coplanar pairs, single triangles) of the two-stage kernel's conservative test."""
-        out = (C.c_int * 3)()
+        """(parallelogram pairs, other coplanar pairs, single triangles, pairs of facing parallelograms) of the
+        two-stage kernel's conservative test."""
+        out = (C.c_int * 4)()
         self._check(lib.bdpt_two_stage_record_counts(self._h, out))
         return tuple(out)
 

@@ -498,7 +498,9 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             const size_t off = cull_walk.size();
             int partner[32];
             for (int k = 0; k < cnt; k++) partner[k] = -1;
-            std::vector<float4> quad_rec, pair_rec;
+            struct Quad { int k, m; float4 c0, pu, pv; bool taken; };
+            std::vector<Quad> quads;
+            std::vector<float4> slab_rec, quad_rec, pair_rec;
             for (int k = 0; k < cnt; k++) {
                 if (partner[k] >= 0) continue;
                 for (int m = k + 1; m < cnt; m++)
@@ -508,12 +510,35 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
                         const float4 *a = &cull[(size_t)(base + k) * 3], *b = &cull[(size_t)(base + m) * 3];
                         float4 pu, pv;
                         if (parallelogram(base + k, base + m, pu, pv))
-                            quad_rec.insert(quad_rec.end(), {a[0], pu, pv, make_float4(cull_s[base + k], bit(k), bit(m), 0.f)});
+                            quads.push_back({k, m, a[0], pu, pv, false});
                         else
                             pair_rec.insert(pair_rec.end(), {a[0], a[1], a[2], b[1], b[2], make_float4(cull_s[base + k], cull_s[base + m], bit(k), bit(m))});
                         break;
                     }
             }
+            /* Two parallelograms that face each other or away from each other, one the other moved along the normal
+             * and cut along the same diagonal: the normals are each other's negative and the coordinate planes
+             * and s are the same numbers (in either order: the test is symmetric in u and v).  Signed zeros
+             * compare equal; they change nothing but the sign of a zero (see same_plane). */
+            for (size_t p = 0; p < quads.size(); p++) {
+                Quad &P = quads[p];
+                if (P.taken) continue;
+                for (size_t q = p + 1; q < quads.size(); q++) {
+                    Quad &Q = quads[q];
+                    if (Q.taken || !(Q.c0.x == -P.c0.x && Q.c0.y == -P.c0.y && Q.c0.z == -P.c0.z)) continue;
+                    if (!(cull_s[base + Q.k] == cull_s[base + P.k])) continue;
+                    const bool direct = same_plane(Q.pu, P.pu) && same_plane(Q.pv, P.pv);
+                    const bool swapped = same_plane(Q.pu, P.pv) && same_plane(Q.pv, P.pu);
+                    if (!direct && !swapped) continue;
+                    P.taken = Q.taken = true;
+                    slab_rec.insert(slab_rec.end(), {P.c0, P.pu, P.pv, make_float4(cull_s[base + P.k], -Q.c0.w, 0.f, 0.f),
+                                                     make_float4(bit(P.k), bit(P.m), bit(Q.k), bit(Q.m))});
+                    break;
+                }
+            }
+            for (const Quad &P : quads)
+                if (!P.taken) quad_rec.insert(quad_rec.end(), {P.c0, P.pu, P.pv, make_float4(cull_s[base + P.k], bit(P.k), bit(P.m), 0.f)});
+            cull_walk.insert(cull_walk.end(), slab_rec.begin(), slab_rec.end());
             cull_walk.insert(cull_walk.end(), quad_rec.begin(), quad_rec.end());
             cull_walk.insert(cull_walk.end(), pair_rec.begin(), pair_rec.end());
             int singles = 0;
@@ -523,7 +548,8 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
                 cull_walk.insert(cull_walk.end(), {a[0], a[1], a[2], make_float4(cull_s[base + k], bit(k), 0.f, 0.f)});
                 singles++;
             }
-            ctx->cull_group[base >> 5] = (uint32_t)off | ((uint32_t)(quad_rec.size() / BDPT_CULL_QUAD_F4) << 16) |
+            ctx->cull_group[base >> 5] = (uint32_t)off | ((uint32_t)(slab_rec.size() / BDPT_CULL_SLAB_F4) << 11) |
+                                         ((uint32_t)(quad_rec.size() / BDPT_CULL_QUAD_F4) << 16) |
                                          ((uint32_t)(pair_rec.size() / BDPT_CULL_PAIR_F4) << 21) | ((uint32_t)singles << 26);
         }
     }
@@ -882,11 +908,12 @@ int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks)
 int bdpt_last_launch_variant(const bdpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
 int bdpt_last_launch_chunks(const bdpt_ctx *ctx) { return ctx ? ctx->last_chunks : 0; }
 
-int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[3])
+int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[4])
 {
     if (!ctx || !out) return BDPT_ERR_INVALID;
-    out[0] = out[1] = out[2] = 0;
+    out[0] = out[1] = out[2] = out[3] = 0;
     for (int g = 0; g * 32 < ctx->n_triangles && g < BDPT_CULL_MAX_TRIANGLES / 32; g++) {
+        out[3] += (int)((ctx->cull_group[g] >> 11) & 0xfu);
         out[0] += (int)((ctx->cull_group[g] >> 16) & 0x1fu);
         out[1] += (int)((ctx->cull_group[g] >> 21) & 0x1fu);
         out[2] += (int)(ctx->cull_group[g] >> 26);

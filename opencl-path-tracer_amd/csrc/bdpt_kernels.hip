@@ -419,7 +419,7 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
         const int cnt = min(32, S.n_triangles - base);
         uint32_t mask = 0u;
         const uint32_t group = S.cull_group[base >> 5];
-        const float4 *c = bdpt_lds + L.cull + (group & 0xffffu);
+        const float4 *c = bdpt_lds + L.cull + (group & 0x7ffu);
         /* the plane part of a triangle's test: val (exact, :286), -1/val... and the approximate point on the plane */
         struct PlaneHit { float val, r, px, py, pz; };
         auto plane_part = [&](const float4 c0) {
@@ -443,6 +443,24 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
             const float z = __builtin_fminf(__builtin_fmaf(-ray_margin, h.r, m), -h.val);
             return !(z < 0.0f);
         };
+        for (int k = (int)((group >> 11) & 0xfu); k > 0; k--, c += BDPT_CULL_SLAB_F4) {      /* stage 1: two opposite walls of a box */
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+            const float val = clm_dot3(d, clm_make3(c0.x, c0.y, c0.z));
+            const bool second = val > 0.0f;                                   /* the ray runs against -n: only the second wall can be hit (:288) */
+            const float num = __builtin_fmaf(-o.z, c0.z, __builtin_fmaf(-o.y, c0.y, __builtin_fmaf(-o.x, c0.x, second ? c3.y : c0.w)));
+            const float r = __builtin_amdgcn_rcpf(val);                       /* second wall: numerator and val both negated, same quotient */
+            const float t = num * r;
+            const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
+            const float u = __builtin_fmaf(pz, c1.z, __builtin_fmaf(py, c1.y, __builtin_fmaf(px, c1.x, c1.w)));
+            const float v = __builtin_fmaf(pz, c2.z, __builtin_fmaf(py, c2.y, __builtin_fmaf(px, c2.x, c2.w)));
+            const float su = c3.x - u, sv = c3.x - v, w = su - v;
+            const float m0 = __builtin_fminf(__builtin_fminf(u, v), w), m1 = __builtin_fminf(__builtin_fminf(su, sv), -w);
+            const float z0 = __builtin_fmaf(ray_margin, __builtin_fabsf(r), m0);   /* |1/val| of the wall that is tested */
+            const float z1 = __builtin_fmaf(ray_margin, __builtin_fabsf(r), m1);
+            mask |= (!(z0 < 0.0f) ? __float_as_uint(second ? c4.z : c4.x) : 0u) | (!(z1 < 0.0f) ? __float_as_uint(second ? c4.w : c4.y) : 0u);
+        }
+        /* two records per trip: one address register, one counter update and one branch for both (1 % of a Cornell launch) */
+#pragma unroll 2
         for (int k = (int)((group >> 16) & 0x1fu); k > 0; k--, c += BDPT_CULL_QUAD_F4) {     /* stage 1: the two halves of a parallelogram */
             const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
             const PlaneHit h = plane_part(c0);

@@ -39,6 +39,12 @@
  *           c0, u, v, (s, mask bit first, mask bit second, -)
  *       u and v are the first triangle's coordinate planes that vanish on its two edges other than the shared
  *       one; the first triangle's coordinates are u, v, s - u - v, the second one's s - u, s - v, u + v - s.
+ *       And in front of those, two such parallelograms in parallel planes that face opposite ways (normals n and
+ *       -n) and have the same u, v and s as numbers -- two opposite walls of a box, cut along the same diagonal
+ *       -- five float4:
+ *           c0 of the first, u, v, (s, -k of the second, -, -), (mask bits: first's halves, second's halves)
+ *       A ray can only hit the one whose normal it runs against (kernel0.cl:288), so the test is made for that
+ *       one alone: with n and k or -k it is, operation for operation, the test of that parallelogram's own record.
  *       A mask bit is 1 << (triangle index - first index of the group), kept as the bits of a float.
  *   surface  2 x float4 : colour, emissive                kernel0.cl:90-94
  * Surface ids live in separate uint32 arrays (read once per query, for the
@@ -53,6 +59,7 @@
 #define BDPT_TRI_F4 6
 #define BDPT_PLN_F4 2
 #define BDPT_CULL_MAX_TRIANGLES 256   /* the two-stage kernel's scenes are bounded by LDS well below this */
+#define BDPT_CULL_SLAB_F4 5
 #define BDPT_CULL_QUAD_F4 4
 #define BDPT_CULL_PAIR_F4 6
 #define BDPT_CULL_SINGLE_F4 4
@@ -67,8 +74,8 @@ struct bdpt_dev_scene {
     const float4 *tri_cull;     /* [cull_f4] records of the conservative test; empty for scenes of more than BDPT_CULL_MAX_TRIANGLES */
     int cull_f4;
     float cull_c;               /* scene constant of that test's margin */
-    /* per group of 32 triangles: offset of its records in tri_cull (float4, bits 0-15), parallelograms (16-20),
-     * other coplanar pairs (21-25), other triangles (26-31) */
+    /* per group of 32 triangles: offset of its records in tri_cull (float4, bits 0-10), pairs of facing
+     * parallelograms (11-14), parallelograms (16-20), other coplanar pairs (21-25), other triangles (26-31) */
     uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32];
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */

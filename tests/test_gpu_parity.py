@@ -450,13 +450,87 @@ def test_two_stage_kernel_parallelogram_pairs_never_drop_a_hit(bdpt, oracle, see
     scene = _quad_walls(bdpt, 34, 16, seed)
     W, H = 64, 48
     ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_LDS2)
-    quads, pairs, singles = ctx.two_stage_record_counts()
-    assert quads >= 16 and pairs >= 2 and singles >= 16 and 2 * (quads + pairs) + singles == len(scene.triangles), (quads, pairs, singles)
+    quads, pairs, singles, slabs = ctx.two_stage_record_counts()
+    assert quads >= 16 and pairs >= 2 and singles >= 16 and 4 * slabs + 2 * (quads + pairs) + singles == len(scene.triangles), (quads, pairs, singles, slabs)
     for s in range(3):
         ctx.render(3)
         oracle.render(st, scene, scene.camera, p, 3, n_threads=8)
         _compare(bdpt, ctx, st, "two-stage, parallelograms %d launch %d:" % (seed, s))
     ctx.close()
+
+
+def _boxes(bdpt, n_boxes, seed):
+    """Cornell box plus boxes with sides along the axes, seen from inside or outside (either winding), every face cut
+    into two triangles along either diagonal with the vertices in any rotation: opposite faces mostly along the same
+    diagonal, some along the other one, some faces wound against the rest of their box, some moved within their plane
+    or made smaller than the face opposite, and the triangles of some boxes in shuffled order."""
+    rng = np.random.default_rng(seed)
+    sc = bdpt.Scene.cornell()
+    tris = []
+    for b in range(n_boxes):
+        c = rng.uniform(-2.0, 2.0, 3).astype(np.float32)
+        h = (10.0 ** rng.uniform(-1.0, 0.3, 3)).astype(np.float32)
+        if b % 2 == 0:                                                  # coordinates that add and subtract without rounding
+            c = np.round(c * 4).astype(np.float32) / 4
+            h = np.float32(2.0) ** np.round(np.log2(h)).astype(np.float32)
+        inward = rng.random() < 0.5
+        box = []
+        for axis in range(3):
+            i, j = [(1, 2), (2, 0), (0, 1)][axis]
+            same_cut = rng.random() < 0.7
+            cut = int(rng.integers(2))
+            for side in (-1, 1):
+                o = c.copy(); o[axis] = c[axis] + side * h[axis]
+                ei = np.zeros(3, np.float32); ei[i] = h[i]
+                ej = np.zeros(3, np.float32); ej[j] = h[j]
+                if side == 1 and b % 5 == 3 and axis == 0:
+                    o = (o + ei * np.float32(0.25)).astype(np.float32)  # moved within its plane
+                if side == 1 and b % 5 == 4 and axis == 1:
+                    ej = (ej * np.float32(0.5)).astype(np.float32)      # smaller than the face opposite
+                corner = [o - ei - ej, o + ei - ej, o + ei + ej, o - ei + ej]     # counter-clockwise seen from +axis
+                this_cut = cut if (same_cut or side == -1) else 1 - cut
+                halves = ([(0, 1, 2), (0, 2, 3)], [(1, 2, 3), (1, 3, 0)])[this_cut]
+                flip = (side == 1) == inward                            # outward normals unless the box is seen from inside
+                if b % 7 == 6 and axis == 2 and side == 1:
+                    flip = not flip                                     # one face against the rest
+                for hv in halves:
+                    r = int(rng.integers(3))
+                    hv = hv[r:] + hv[:r]
+                    if flip:
+                        hv = (hv[0], hv[2], hv[1])
+                    box.append([corner[k] for k in hv])
+        if b % 3 == 2:
+            rng.shuffle(box)
+        tris += box
+    tri = np.zeros(len(tris), bdpt.triangle_dtype)
+    for i, t in enumerate(tris):
+        tri["p0"][i, :3], tri["p1"][i, :3], tri["p2"][i, :3] = t
+    tri["surface"] = rng.choice([0, 1, 3, 4], len(tris))
+    sc.triangles = np.concatenate([sc.triangles, tri])
+    return sc
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_two_stage_kernel_opposite_walls_never_drop_a_hit(bdpt, oracle, seed):
+    """Two opposite walls of a box, cut along the same diagonal, share one record of the conservative test: a ray is
+    tested against the one whose normal it runs against.  Every id, count and bit as the oracle, for boxes seen from
+    inside and from outside, with the exceptions that must fall back to records of their own."""
+    scene = _boxes(bdpt, 7, seed)
+    W, H = 64, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_LDS2)
+    quads, pairs, singles, slabs = ctx.two_stage_record_counts()
+    assert slabs >= 8 and quads >= 4 and 4 * slabs + 2 * (quads + pairs) + singles == len(scene.triangles), (quads, pairs, singles, slabs)
+    for s in range(3):
+        ctx.render(3)
+        oracle.render(st, scene, scene.camera, p, 3, n_threads=8)
+        _compare(bdpt, ctx, st, "two-stage, boxes %d launch %d:" % (seed, s))
+    ctx.close()
+
+
+def test_the_cornell_box_is_three_pairs_of_opposite_walls(bdpt):
+    with bdpt.Context(32, 32) as ctx:
+        ctx.upload_scene(bdpt.Scene.cornell())
+        assert ctx.two_stage_record_counts() == (0, 0, 0, 3)
 
 
 def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):

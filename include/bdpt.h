@@ -17,6 +17,7 @@
 #ifndef BDPT_H
 #define BDPT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -305,6 +306,11 @@ int bdpt_query_rays_noalloc(bdpt_ctx *ctx, const float *rays, const int32_t *ori
  * For checking that device and host arithmetic agree bit for bit. */
 int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n);
 
+/* Limit, in bytes, of the device memory the context may take to keep the order of a launch's samples (class
+ * order, bdpt_params.sample_order): width x height x max_light_bounces x ceil(spp / 32) words, allocated by the
+ * first launch that needs them and kept.  A launch that would need more works the order out as it goes: slower
+ * (9 % for 1024 samples of the Cornell box), same result.  Default 8 GiB; 0 = never.  No reference counterpart. */
+int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes);
 /* BDPT_KERNEL_* that the last launch ran (what AUTO resolved to), 0 before the first launch. */
 int bdpt_last_launch_variant(const bdpt_ctx *ctx);
 /* How the uploaded scene's triangles are grouped for the two-stage kernel's conservative test: out[0] pairs that

@@ -107,6 +107,7 @@ lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int
 lib.bdpt_set_launch_chunks.argtypes = [_vp, C.c_int]
 lib.bdpt_last_launch_chunks.argtypes = [_vp]
 lib.bdpt_two_stage_record_counts.argtypes = [_vp, C.POINTER(C.c_int)]
+lib.bdpt_set_order_scratch_limit.argtypes = [_vp, C.c_size_t]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
 lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
@@ -429,6 +430,10 @@ class Context:
     def set_launch_chunks(self, chunks):
         """Runs per tile of a render call (0 = chosen per launch, 1 = unsliced); never changes a result."""
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
+
+    def set_order_scratch_limit(self, nbytes):
+        """Device memory the context may take for the table that keeps a launch's class order (0: none); never changes a result."""
+        self._check(lib.bdpt_set_order_scratch_limit(self._h, nbytes))
 
     def two_stage_record_counts(self):
         """(parallelogram pairs, other coplanar pairs, single triangles, pairs of facing parallelograms) of the

@@ -26,6 +26,9 @@
 #include "bdpt_kernels.h"
 #include "bdpt_layout.h"
 
+/* memory a context may take for the class order of a launch unless told otherwise (bdpt_set_order_scratch_limit) */
+#define BDPT_ORDER_SCRATCH_DEFAULT ((size_t)8 << 30)
+
 struct bdpt_ctx {
     int device = 0;
     int width = 0, height = 0;
@@ -67,6 +70,9 @@ struct bdpt_ctx {
     unsigned long long *d_counters = nullptr;
     uint32_t *d_slice_sync = nullptr;  /* sliced launches: ticket counter + one word per workgroup tile */
     uint4 *d_slice_cursor = nullptr;   /* ... and a sample cursor per pixel */
+    uint32_t *d_class_masks = nullptr; /* class order from a table (bdpt_kargs.class_masks), allocated by the first launch that wants it */
+    size_t class_mask_bytes = 0;       /* its size */
+    size_t order_scratch_limit = BDPT_ORDER_SCRATCH_DEFAULT;   /* bdpt_set_order_scratch_limit */
     int slice_tiles = 0;               /* tiles d_slice_sync has room for */
     int launch_chunks = 0;             /* bdpt_set_launch_chunks: 0 = chosen per launch */
     bool sliced_unchecked = false;     /* a sliced launch was issued and its give-up mark has not been read yet */
@@ -220,6 +226,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
     dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters); dev_free(ctx->d_slice_sync); dev_free(ctx->d_slice_cursor);
+    dev_free(ctx->d_class_masks);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -856,6 +863,27 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         K.chunk_spp = (spp + chunks - 1) / chunks;
         K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
     }
+    /* Class order from a table: one mask word per class and 32 samples of every pixel of the frame.  The table is
+     * kept from launch to launch and grows when a launch needs more; a launch whose table would exceed the limit, or
+     * that could not get the memory (or may not ask for it: a stream under capture), classifies on the fly. */
+    if (K.reorder && ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && variant != BDPT_KERNEL_TILED && K.max_l <= 7) {
+        const size_t words = ((size_t)spp + 31) / 32;
+        const size_t bytes = (size_t)ctx->width * ctx->height * (size_t)K.max_l * words * sizeof(uint32_t);
+        if (bytes <= ctx->order_scratch_limit) {
+            if (bytes > ctx->class_mask_bytes) {
+                hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(ctx->stream, &capturing) != hipSuccess) (void)hipGetLastError();
+                if (capturing == hipStreamCaptureStatusNone) {
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          /* an earlier launch may still read the old table */
+                    dev_free(ctx->d_class_masks);
+                    ctx->class_mask_bytes = 0;
+                    if (hipMalloc((void **)&ctx->d_class_masks, bytes) == hipSuccess) ctx->class_mask_bytes = bytes;
+                    else { ctx->d_class_masks = nullptr; (void)hipGetLastError(); }
+                }
+            }
+            if (bytes <= ctx->class_mask_bytes) { K.class_masks = ctx->d_class_masks; K.mask_words = (int)words; }
+        }
+    }
     if (K.n_chunks > 1) ctx->sliced_unchecked = true;
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
@@ -902,6 +930,13 @@ int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks)
     if (!ctx) return BDPT_ERR_INVALID;
     if (chunks < 0 || chunks > 4096) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_launch_chunks: 0 (automatic) to 4096");
     ctx->launch_chunks = chunks;
+    return BDPT_OK;
+}
+
+int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    ctx->order_scratch_limit = bytes;
     return BDPT_OK;
 }
 

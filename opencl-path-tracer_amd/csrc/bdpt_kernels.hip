@@ -147,6 +147,89 @@ BDPT_DEV void cursor_store(const SampleCursor &c, const bdpt_kargs &K, size_t pi
     state_store(true, &K.slice_cursor[pix], make_uint4((uint32_t)c.cls, (uint32_t)c.head, c.st_head, c.pending));
 }
 
+/*
+ * Class order from a table.  Finding a pixel's samples of one class by classifying its sample indices (cursor_rounds)
+ * looks at every index once per class, and a look is five integer multiplications: 9 % of a 1024-sample launch of the
+ * Cornell box.  Here a pixel's indices are classified once, before its first sample, 32 at a time, and kept as one
+ * bit mask per class and 32 indices (K.class_masks); taking the next sample is then a count of trailing zeros, and
+ * a load when a word is used up.  The samples come in the same order, class by class and index ascending.
+ *
+ * plane[k] collects, index by index, whether roulette draw k stops the walk; class c < max_l is "draw c - 1 stops and
+ * none before it", class max_l is "none of the first max_l - 1 stops".  N as in roulette_class: N + 1 >= max_l.
+ */
+constexpr uint32_t kWordStride = pow_u32_c(kSampleStride, 32);
+
+template <int N>
+BDPT_DEV void cursor_fill_masks(const bdpt_kargs &K, bool shared, size_t pix, uint32_t seed)
+{
+    const bool five = sampler_draws_four(K.sampler);
+    const uint32_t step = five ? lcg_pow(5) : lcg_pow(4), lead = five ? lcg_pow(10) : lcg_pow(9);
+    const size_t npix = (size_t)K.width * K.height;
+    uint32_t st = cursor_first_state(K, seed);
+    for (int w = 0; w < K.mask_words; w++) {
+        uint32_t plane[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) plane[k] = 0u;
+        for (int b = 0; b < 32; b++) {
+            uint32_t x = st * lead;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                plane[k] = (plane[k] >> 1) | (x > K.fate_above ? 0x80000000u : 0u);      /* kernel0.cl:788 */
+                x *= step;
+            }
+            st *= kSampleStride;
+        }
+        const int left = K.spp - w * 32;                                       /* at least 1 */
+        uint32_t open = left >= 32 ? ~0u : (1u << left) - 1u;                  /* indices of the launch that no earlier draw has stopped */
+#pragma unroll
+        for (int c = 1; c <= N + 1; c++) {
+            if (c <= K.max_l) {
+                const uint32_t stops_here = c <= N ? plane[c <= N ? c - 1 : 0] : 0u;
+                const uint32_t m = c == K.max_l ? open : open & stops_here;
+                state_store(shared, &K.class_masks[((size_t)(c - 1) * K.mask_words + w) * npix + pix], m);
+                open &= ~stops_here;
+            }
+        }
+    }
+}
+
+/* cursor_next for a launch with the table: c.head = next word to load, c.st_head = start state of sample 32 * head,
+ * c.pending = what is left of word head - 1 */
+BDPT_DEV bool cursor_next_masks(SampleCursor &c, const bdpt_kargs &K, size_t pix, const uint32_t *seed_w, uint32_t &start)
+{
+    const size_t npix = (size_t)K.width * K.height;
+    while (__builtin_amdgcn_ballot_w64(c.pending == 0u && c.cls >= 1) != 0) {
+        const bool empty = c.pending == 0u && c.cls >= 1;
+        const bool used_up = empty && c.head >= K.mask_words;                 /* no more samples of this class */
+        if (__builtin_amdgcn_ballot_w64(used_up) != 0) {
+            asm volatile("");                                                 /* a real branch: a handful of times per launch */
+            if (used_up) {
+                c.cls--;
+                c.head = 0;
+                c.st_head = cursor_first_state(K, *seed_w);
+            }
+            continue;                                                         /* the lane may have run out of classes */
+        }
+        uint32_t word = 0u;
+        if (empty) word = K.class_masks[((size_t)(c.cls - 1) * K.mask_words + c.head) * npix + pix];
+        c.pending = empty ? word : c.pending;
+        c.head += empty ? 1 : 0;
+        c.st_head = empty ? c.st_head * kWordStride : c.st_head;
+    }
+    if (c.cls < 1) return false;
+    const int b = __builtin_ctz(c.pending);
+    c.pending &= c.pending - 1u;
+    start = c.st_head * kStrideInvPow.v[32 - b];             /* back from sample 32 * head to sample 32 * (head - 1) + b */
+    return true;
+}
+
+/* the next sample of a pixel, whichever way the launch keeps its order */
+BDPT_DEV bool sample_next(SampleCursor &c, const bdpt_kargs &K, size_t pix, uint32_t &start)
+{
+    if (K.class_masks && c.cls >= 0) return cursor_next_masks(c, K, pix, &K.seed_w[pix], start);
+    return cursor_next(c, K, &K.seed_w[pix], start);
+}
+
 /* what a run leaves in memory for the next run or the next launch */
 template <bool AOV>
 BDPT_DEV void pixel_state_store(const bdpt_kargs &K, const Slice &sl, size_t pix, const float acc[4], uint32_t w, const SampleCursor &cur,
@@ -745,7 +828,11 @@ BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
     T.clk[11] = clock64() - pixel_t0;
 #endif
     BDPT_PHASE_BEGIN;
-    for (int s = sl.s0; s < sl.s1 && cursor_next(cur, K, &K.seed_w[pix], start); s++) {   /* s counts the samples taken so far */
+    if (K.class_masks && sl.s0 == 0 && cur.cls >= 1) {
+        if (K.max_l <= 5) cursor_fill_masks<4>(K, sl.shared, pix, seed);
+        else cursor_fill_masks<6>(K, sl.shared, pix, seed);
+    }
+    for (int s = sl.s0; s < sl.s1 && sample_next(cur, K, pix, start); s++) {   /* s counts the samples taken so far */
         BDPT_PHASE_END(10);
         const int n = K.num_samples + s;                                  /* kernel0.cl:588 */
         if (K.rng_mode == BDPT_RNG_STRIDED) w = start;

@@ -107,6 +107,11 @@ struct bdpt_kargs {
      * runs.  n_tiles = workgroups of the unsliced grid, wg_x of them per row of the region. */
     uint32_t *slice_sync;
     uint4 *slice_cursor;
+    /* Class order from a table (cursor_fill_masks in bdpt_kernels.hip): word w of class c of pixel p, at
+     * ((c - 1) * mask_words + w) * width * height + p, has bit b set when sample 32 w + b of the launch is of class c.
+     * Null: the classes are worked out again for every class (cursor_rounds in bdpt_device.h). */
+    uint32_t *class_masks;
+    int mask_words;
     int n_chunks, chunk_spp, n_tiles, wg_x;
     int block;                  /* threads per workgroup, 64 or 128: one 8x8-pixel tile per wavefront, side by side (set by the launcher) */
     int num_samples;            /* imgDesc.numSamples before the first sample */

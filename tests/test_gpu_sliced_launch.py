@@ -18,9 +18,14 @@ MODES = {
 }
 
 
-def _render(bdpt, scene, params, chunks, calls, region=None, interleave=None, counters=False, size=None):
+def _render(bdpt, scene, params, chunks, calls, region=None, interleave=None, counters=False, size=None, order_scratch=None,
+            sample_offset=0):
     w, h = size or (W, H)
     with bdpt.Context(w, h) as ctx:
+        if order_scratch is not None:
+            ctx.set_order_scratch_limit(order_scratch)
+        if sample_offset:
+            ctx.set_sample_offset(sample_offset)
         ctx.set_params(params)
         ctx.upload_scene(scene)
         ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
@@ -141,6 +146,7 @@ def test_benchmark_sized_launch_sliced_automatically(bdpt):
         ctx.upload_scene(scene)
         ctx.upload_seeds(bdpt.make_seeds(size[0], size[1], 0x5EED))
         ctx.set_camera(scene.camera)
+        ctx.set_launch_chunks(0)                       # automatic, whatever BDPT_LAUNCH_CHUNKS says
         ctx.render(1024)
         assert ctx.last_launch_chunks() == 16 and ctx.last_launch_variant() == bdpt.KERNEL_LDS2
         sliced = ctx.read_accum()
@@ -160,3 +166,23 @@ def test_launch_chunks_argument_is_checked(bdpt):
         with pytest.raises(bdpt.BdptError):
             ctx.set_launch_chunks(100000)
         ctx.set_launch_chunks(0)
+
+
+@pytest.mark.parametrize("variant", [1, 3, 5])
+@pytest.mark.parametrize("order", ["strided_sum_class", "strided_sum_adaptive"])
+def test_class_order_from_the_table_is_the_order_worked_out_on_the_fly(bdpt, variant, order):
+    """A launch keeps the classes of its samples in a table in device memory when it may have the memory
+    (bdpt_set_order_scratch_limit), and works them out class by class when not: same order, so the same bits, for
+    sample counts that end inside a mask word, launches that continue a frame, a sample offset, more subpath
+    vertices than the default, sliced and not."""
+    scene = bdpt.Scene.cornell()
+    for extra in (dict(), dict(max_light_bounces=7), dict(max_light_bounces=2), dict(max_light_bounces=1)):
+        p = bdpt.default_params(kernel_variant=variant, aov_enable=1, **MODES[order], **extra)
+        for chunks, calls, offset in ((1, (70, 5, 33), 0), (4, (70, 64), 0), (3, (45,), 1000)):
+            table = _render(bdpt, scene, p, chunks, calls, counters=False, sample_offset=offset)
+            none = _render(bdpt, scene, p, chunks, calls, counters=False, sample_offset=offset, order_scratch=0)
+            _same(table, none, "%s, variant %d, %s, %d runs" % (order, variant, extra, chunks))
+    # a limit just too small for the second launch: the first uses the table, the second does not
+    p = bdpt.default_params(kernel_variant=variant, **MODES[order])
+    words_32 = W * H * p.max_light_bounces * 4
+    _same(_render(bdpt, scene, p, 2, (32, 33), order_scratch=words_32), _render(bdpt, scene, p, 2, (32, 33), order_scratch=0), "limit between two launches")

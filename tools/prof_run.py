@@ -21,6 +21,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mode", default="strided")
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--chunks", type=int, default=0, help="bdpt_set_launch_chunks (0 = automatic, 1 = unsliced)")
+ap.add_argument("--order-scratch", type=int, default=-1, help="bdpt_set_order_scratch_limit in MiB (-1 = the default)")
 a = ap.parse_args()
 
 if a.scene.startswith("soup:"):
@@ -36,6 +37,8 @@ ctx.upload_scene(scene)
 ctx.upload_seeds(bdpt.make_seeds(a.width, a.height, 0x5EED))
 ctx.set_camera(scene.camera)
 ctx.set_launch_chunks(a.chunks)
+if a.order_scratch >= 0:
+    ctx.set_order_scratch_limit(a.order_scratch << 20)
 ctx.render(min(a.spp, 8))
 ms = []
 for _ in range(a.launches):

@@ -559,9 +559,6 @@ BDPT_DEV bool cursor_next(SampleCursor &c, const bdpt_kargs &K, const uint32_t *
         c.head++;
         return true;
     }
-#ifdef BDPT_CURSOR_TWICE   /* timing experiment: the rounds run twice, the first time on a copy that is thrown away */
-    { SampleCursor c2 = c; uint32_t st2 = 0; const bool r2 = cursor_rounds<4>(c2, K, seed_w, st2); asm volatile("" ::"v"(st2), "v"(c2.pending), "v"(c2.head), "v"((int)r2)); }
-#endif
     if (K.max_l <= 5) return cursor_rounds<4>(c, K, seed_w, start);
     if (K.max_l <= 7) return cursor_rounds<6>(c, K, seed_w, start);
     return cursor_rounds<0>(c, K, seed_w, start);

@@ -150,22 +150,20 @@ CLM_FN float clm_asin_core(float s, float z)
     return clm_fma(s * z, p, s);
 }
 
-/* acos(float) on [-1, 1]. */
+/* acos(float) on [-1, 1]: beyond +-0.5 through asin(sqrt((1 - |x|) / 2)).  One evaluation of the root and of the
+ * polynomial whatever the range (the arguments are selected, not the code path): on a GPU the lanes of a
+ * wavefront fall into all three ranges at once. */
 CLM_FN float clm_acosf(float x)
 {
     const float PI_F = 0x1.921fb6p+1f;
     const float PIO2_F = 0x1.921fb6p+0f;
-    if (x > 0.5f) {
-        float z = 0.5f * (1.0f - x);
-        float s = clm_sqrt(z);
-        return 2.0f * clm_asin_core(s, z);
-    }
-    if (x < -0.5f) {
-        float z = 0.5f * (1.0f + x);
-        float s = clm_sqrt(z);
-        return PI_F - 2.0f * clm_asin_core(s, z);
-    }
-    return PIO2_F - clm_asin_core(x, x * x);
+    const float ax = x < 0.0f ? -x : x;
+    const int outer = ax > 0.5f;
+    const float z = outer ? 0.5f * (1.0f - ax) : x * x;
+    const float s = outer ? clm_sqrt(z) : x;
+    const float a = clm_asin_core(s, z);
+    if (!outer) return PIO2_F - a;
+    return x > 0.0f ? 2.0f * a : PI_F - 2.0f * a;
 }
 
 /* sqrt(binary64) from a binary32 seed and two Newton steps (only + * /). */

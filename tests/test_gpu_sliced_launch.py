@@ -182,6 +182,10 @@ def test_class_order_from_the_table_is_the_order_worked_out_on_the_fly(bdpt, var
             table = _render(bdpt, scene, p, chunks, calls, counters=False, sample_offset=offset)
             none = _render(bdpt, scene, p, chunks, calls, counters=False, sample_offset=offset, order_scratch=0)
             _same(table, none, "%s, variant %d, %s, %d runs" % (order, variant, extra, chunks))
+    # a region that starts off the tile grid, and tiles dealt to one of three shares
+    p = bdpt.default_params(kernel_variant=variant, aov_enable=1, **MODES[order])
+    for kw in (dict(region=(9, 5, 61, 40)), dict(interleave=(32, 16, 3, 1)), dict(region=(16, 8, 64, 40), interleave=(16, 8, 2, 1))):
+        _same(_render(bdpt, scene, p, 3, (45, 20), **kw), _render(bdpt, scene, p, 3, (45, 20), order_scratch=0, **kw), "%s, %s" % (order, kw))
     # a limit just too small for the second launch: the first uses the table, the second does not
     p = bdpt.default_params(kernel_variant=variant, **MODES[order])
     words_32 = W * H * p.max_light_bounces * 4

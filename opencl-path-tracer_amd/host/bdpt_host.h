@@ -125,6 +125,8 @@ public:
     float lastLaunchMs();
     /* runs per tile of a render call (bdpt_set_launch_chunks): 0 chosen per launch, 1 unsliced; every device of a group */
     void setLaunchChunks(int chunks);
+    /* device memory a context may take to keep a launch's sample order (bdpt_set_order_scratch_limit); every device of a group */
+    void setOrderScratchLimit(size_t bytes);
     bdpt_ctx *ctx() { return c; }
     bdpt_group *group() { return g; }
     int numDevices() const;

@@ -9,7 +9,7 @@
  *             [--obj model.obj [--obj-surface I] [--obj-scale S] [--obj-translate X,Y,Z]]
  *             [--width W] [--height H] [--frames F] [--spp S] [--orbit-frames K]
  *             [--seed G] [--device D | --devices D0,D1,... [--combine auto|rccl|copy]]
- *             [--out image.pfm|.ppm|.png [--gamma G]] [--quiet] [--launch-chunks C]
+ *             [--out image.pfm|.ppm|.png [--gamma G]] [--quiet] [--launch-chunks C] [--order-scratch-mib M]
  *             [--resume state.ckpt] [--checkpoint state.ckpt]
  */
 #include <chrono>
@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     uint32_t seed = 0x5EEDu;
     bool quiet = false;
     int launch_chunks = 0;
+    long order_scratch_mib = -1;                    /* --order-scratch-mib: -1 = the library's default */
     std::vector<int> devices;                       /* --devices: several GPUs, each frame's samples dealt to them */
     int combine = BDPT_COMBINE_AUTO;
     for (int i = 1; i < argc; i++) {
@@ -82,6 +83,7 @@ int main(int argc, char **argv)
             }
         }
         else if (!std::strcmp(argv[i], "--launch-chunks")) launch_chunks = std::atoi(next("--launch-chunks"));
+        else if (!std::strcmp(argv[i], "--order-scratch-mib")) order_scratch_mib = std::atol(next("--order-scratch-mib"));
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else { std::fprintf(stderr, "ERROR: unknown argument %s\n", argv[i]); return EXIT_FAILURE; }
     }
@@ -116,6 +118,7 @@ int main(int argc, char **argv)
                     bdpt_group_combine(r.group()) == BDPT_COMBINE_RCCL ? "an RCCL reduce" : "device-to-device copies");
     r.verbose = !quiet;
     if (launch_chunks != 0) r.setLaunchChunks(launch_chunks);
+    if (order_scratch_mib >= 0) r.setOrderScratchLimit((size_t)order_scratch_mib << 20);
     r.setScene(scene);
     r.setSeeds(seed);
     if (!resume_path.empty()) {

@@ -180,6 +180,12 @@ void Renderer::setLaunchChunks(int chunks)
         check(bdpt_set_launch_chunks(g ? bdpt_group_member(g, i) : c, chunks), "bdpt_set_launch_chunks");
 }
 
+void Renderer::setOrderScratchLimit(size_t bytes)
+{
+    for (int i = 0; i < numDevices(); i++)
+        check(bdpt_set_order_scratch_limit(g ? bdpt_group_member(g, i) : c, bytes), "bdpt_set_order_scratch_limit");
+}
+
 bool write_pfm(const std::string &path, const float *rgba, int width, int height)
 {
     FILE *f = std::fopen(path.c_str(), "wb");

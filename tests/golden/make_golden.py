@@ -105,10 +105,57 @@ def region_cases():
     assert (eye[..., 1] >= 12).any(), "the region must see soup triangles"
 
 
+def render_launch_case(name, scene, recipe, W, H, region, spp, seed, sample_offset, **pkw):
+    """A region of a large frame rendered as ONE launch of `spp` samples (the order in which a STRIDED + SUM launch
+    adds its samples is part of the result), with a sample offset as a rank of a sample split has.  Keeps the
+    region's crop of every output after the launch."""
+    x0, y0, w, h = region
+    seeds = bdpt.make_seeds(W, H, seed)
+    p = bdpt.default_params(aov_enable=1, **pkw)
+    st = oracle.State(W, H, seeds)
+    oracle.render(st, scene, scene.camera, p, spp, region=region, sample_offset=sample_offset, n_threads=8)
+    crop = lambda a: a[y0:y0 + h, x0:x0 + w].copy()
+    out = dict(width=np.asarray(W), height=np.asarray(H), spp=np.asarray(spp), region=np.asarray(region),
+               sample_offset=np.asarray(sample_offset), global_seed=np.asarray(seed), scene_kind=np.asarray(recipe[0]),
+               n_soup=np.asarray(recipe[1]), soup_seed=np.asarray(recipe[2]), camera=np.asarray(scene.camera),
+               seed_words_after=region_seed_words(st.seeds, W, H, region), out_eye_hit=crop(st.eye_hit),
+               out_hit_hash=crop(st.hit_hash), out_radiance=crop(st.radiance), out_accum=crop(st.accum),
+               out_rng_draws=crop(st.rng_draws), out_rays=crop(st.rays), **params_dict(p))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    return st
+
+
+def c3_cases():
+    """The outdoor sphere arrangement on its own 3840x2160 frame, as one rank of an 8-way sample split renders it:
+    STRIDED + SUM, one launch of 8 samples, first sample index 0 (rank 0) and 896 (rank 7 of 8 x 128).  64x64 regions:
+    on the upper silhouette of a sphere, where four spheres meet around a hole the light shows through, and the frame's bottom-right
+    corner (every eye ray leaves the scene; x*2160 + y at its largest)."""
+    outdoor = bdpt.Scene.outdoor()
+    W, H = 3840, 2160
+    kw = dict(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM)
+    for label, region in (("silhouette_1712_528", (1712, 528, 64, 64)), ("junction_1956_1060", (1956, 1060, 64, 64)),
+                          ("corner_3776_2096", (3776, 2096, 64, 64))):
+        for off in (0, 896):
+            st = render_launch_case("launch4k_c3_%s_from%d" % (label, off), outdoor, (bdpt.SCENE_OUTDOOR, 0, 0), W, H, region,
+                                    8, 0x5EED, off, **kw)
+            x0, y0, w, h = region
+            eye = st.eye_hit[y0:y0 + h, x0:x0 + w]
+            if label.startswith("silhouette"):
+                assert (eye[..., 0] < 0).any() and (eye[..., 0] == 0).any()
+            elif label.startswith("junction"):
+                assert len(np.unique(eye[..., 1][eye[..., 0] == 0])) >= 3 and st.accum[y0:y0 + h, x0:x0 + w].max() > 0
+            else:
+                assert (eye[..., 0] < 0).all()
+
+
 def main():
+    if "--c3-only" in sys.argv:
+        c3_cases()
+        return
     if "--regions-only" not in sys.argv:
         small_cases()
     region_cases()
+    c3_cases()
     print("fixtures written to", HERE)
 
 

@@ -10,6 +10,7 @@ RENDER_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G
 
 
 REGION_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "region_*.npz")))
+LAUNCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "launch4k_*.npz")))
 
 
 def load(name):

@@ -82,3 +82,40 @@ def test_region_of_the_1080p_frame_matches_golden(bdpt, case, variant):
         acc = ctx.read_accum()
         acc[y0:y0 + h, x0:x0 + w] = 0
         assert not acc.any()
+
+
+@pytest.mark.parametrize("case,variant", [(c, v) for c in gu.LAUNCH_CASES for v in [0, 1, 3, 4]])
+def test_region_of_the_4k_outdoor_frame_matches_golden(bdpt, case, variant):
+    """The outdoor sphere arrangement on its 3840x2160 frame as one rank of an 8-way sample split renders it (STRIDED +
+    SUM, one launch of 8 samples, first sample index 0 or 896): 64x64 regions on a sphere's silhouette, where four
+    spheres meet, and in the frame's bottom-right corner.  Pixel coordinates with the fp64 aspect at 3840/2160 and the
+    seed index x*2160 + y (kernel0.cl:590, :600-604); AUTO must take the LDS kernel (no triangles)."""
+    g = gu.load(case)
+    scene, p, W, H, spp, region, seed = gu.unpack_region(bdpt, g)
+    assert (W, H) == (3840, 2160) and p.rng_mode == bdpt.RNG_STRIDED and p.accum_mode == bdpt.ACCUM_SUM
+    x0, y0, w, h = region
+    p.kernel_variant = variant
+    crop = lambda a: a[y0:y0 + h, x0:x0 + w]
+    seeds = bdpt.make_seeds(W, H, seed)
+    with bdpt.Context(W, H) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(seeds)
+        ctx.set_camera(scene.camera)
+        ctx.set_region(*region)
+        ctx.set_sample_offset(int(g["sample_offset"]))
+        ctx.render(spp)
+        if variant == 0:
+            assert ctx.last_launch_variant() == bdpt.KERNEL_LDS
+        assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_EYE_HIT)), g["out_eye_hit"])
+        assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_HIT_HASH)), g["out_hit_hash"])
+        assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RNG_DRAWS)), g["out_rng_draws"])
+        assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RAYS)), g["out_rays"])
+        assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RADIANCE)).view(np.uint32), g["out_radiance"].view(np.uint32))
+        acc = ctx.read_accum()
+        assert np.array_equal(crop(acc).view(np.uint32), g["out_accum"].view(np.uint32))
+        xs, ys = np.meshgrid(np.arange(x0, x0 + w), np.arange(y0, y0 + h))
+        assert np.array_equal(ctx.read_seeds()[(xs * H + ys) * 4 + 3], g["seed_words_after"])
+        assert np.array_equal(g["seed_words_after"], seeds[(xs * H + ys) * 4 + 3])      # STRIDED: the seeds stay
+        acc[y0:y0 + h, x0:x0 + w] = 0
+        assert not acc.any()

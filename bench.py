@@ -157,7 +157,7 @@ def main():
     ctx.set_camera(scene.camera)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     ctx.bind_accum(accum.data_ptr())
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # launches, the reduce and the events below: one stream
+    ctx.follow_stream(torch.cuda.current_stream().cuda_stream)   # launches, the reduce and the events below: one stream
 
     launch_ms, reduce_ms = [], []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

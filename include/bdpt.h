@@ -185,7 +185,11 @@ int bdpt_get_params(const bdpt_ctx *ctx, bdpt_params *p);
 /* cl::Buffer creation + blocking enqueueWriteBuffer of spheres, planes,
  * triangles, GeometryDescriptor and surfaces (main.cpp:424-446, :534-539).
  * The arrays are copied and re-laid out before return; null pointers are
- * allowed for zero counts.  Resets the sample counter. */
+ * allowed for zero counts.  Resets the sample counter.
+ * The fourth component of every centre, vertex, normal and point must be 0, as in the reference's own scene
+ * (main.cpp:282-394): the reference's dot / distance / length are four-component operations (kernel0.cl:331,
+ * :336, :398), so any other w changes its image in a way this library does not follow; such a scene is refused
+ * (BDPT_ERR_INVALID).  Colours and emissive values use all four components. */
 int bdpt_upload_scene(bdpt_ctx *ctx,
                       const bdpt_sphere *spheres, int n_spheres,
                       const bdpt_plane *planes, int n_planes,
@@ -198,7 +202,7 @@ int bdpt_upload_seeds(bdpt_ctx *ctx, const uint32_t *seeds);
 int bdpt_read_seeds(bdpt_ctx *ctx, uint32_t *seeds);
 
 /* Camera upload; like the reference it also zeroes the sample counter
- * (main.cpp:150-156, :524-533). */
+ * (main.cpp:150-156, :524-533).  pos[3], look_at[3] and up[3] must be 0 (camera.cpp:137-139), else BDPT_ERR_INVALID. */
 int bdpt_set_camera(bdpt_ctx *ctx, const bdpt_camera *cam);
 
 /* ImageDescriptor write + kernel launch + wait + numSamples += spp
@@ -241,6 +245,14 @@ int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, 
 int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks);
 /* runs per tile the last render call asked its launch for (1 = unsliced) */
 int bdpt_last_launch_chunks(const bdpt_ctx *ctx);
+/* A run of a sliced launch waits for the run before it on the same tile.  That wait always ends unless something
+ * else has gone wrong on the device; as a guard, a workgroup that has waited longer than a limit gives up, the rest of
+ * the launch drains without touching the image, and the next call that waits for the launch (bdpt_sync, bdpt_render,
+ * bdpt_read_accum / _aov / _seeds / _counters, bdpt_last_launch_ms) or the next bdpt_render_async returns
+ * BDPT_ERR_HIP once: the image is incomplete, reset with bdpt_set_camera and render again.  seconds = 0 (the
+ * default): the limit is a hundred times the launch's expected duration, at least a minute.  No reference
+ * counterpart. */
+int bdpt_set_slice_wait_limit(bdpt_ctx *ctx, double seconds);
 
 /* Interop with a caller that owns device memory and streams (torch):
  * render on `hip_stream` (NULL = the context's own stream), and accumulate into
@@ -288,12 +300,13 @@ int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[BDPT_N_COUNTERS]);
 int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n,
                     int32_t *out_ids, float *out_pos, float *out_normal);
 
-/* bdpt_query_rays for callers that must not allocate device memory (code between the begin and end of a
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+/* bdpt_query_rays for callers that must not allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc, processes whose memory pool is fully committed).  It has no counterpart in the
  * reference.  Same arguments and results as bdpt_query_rays, which allocates and frees five device buffers
  * per call; this one stages rays and results in a fixed array that is part of the library's code object
  * (4 MiB on every GPU the library is loaded on, held until the process ends) and calls no hipMalloc /
- * hipFree.  n may be at most BDPT_QUERY_NOALLOC_MAX_RAYS; more is BDPT_ERR_INVALID.  All contexts on one
+ * hipFree.  It allocates nothing, but it is not capturable: it copies from and to the caller's host buffers
+ * and waits for the stream before it returns, neither of which a stream under HIP graph capture allows.  n may be at most BDPT_QUERY_NOALLOC_MAX_RAYS; more is BDPT_ERR_INVALID.  All contexts on one
  * GPU share that array: calls that overlap in time on one GPU (from several threads, or several contexts
  * on different streams) race and must be serialised by the caller. */
 #define BDPT_QUERY_NOALLOC_MAX_RAYS 65536
@@ -308,9 +321,15 @@ int bdpt_clmath_eval(bdpt_ctx *ctx, int op, const double *in, double *out, int n
 
 /* Limit, in bytes, of the device memory the context may take to keep the order of a launch's samples (class
  * order, bdpt_params.sample_order): width x height x max_light_bounces x ceil(spp / 32) words, allocated by the
- * first launch that needs them and kept.  A launch that would need more works the order out as it goes: slower
- * (9 % for 1024 samples of the Cornell box), same result.  Default 8 GiB; 0 = never.  No reference counterpart. */
+ * first launch that needs them and kept until the context is destroyed (1.3 GB for 1920x1080 x 1024 samples,
+ * 5.3 GB for 3840x2160 x 1024).  That first bdpt_render_async waits for the stream and allocates before it
+ * enqueues.  A launch that would need more than the limit, or more than half of the device memory that is free at
+ * that moment, works the order out as it goes: slower (9 % for 1024 samples of the Cornell box), same result;
+ * bdpt_last_launch_order_table tells which.  Default 8 GiB; 0 = never.  No reference counterpart. */
 int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes);
+/* 1 if the last launch took its class order from that table, 0 if it worked the order out as it went (no table
+ * wanted, over the limit, or the memory was not to be had). */
+int bdpt_last_launch_order_table(const bdpt_ctx *ctx);
 /* BDPT_KERNEL_* that the last launch ran (what AUTO resolved to), 0 before the first launch. */
 int bdpt_last_launch_variant(const bdpt_ctx *ctx);
 /* How the uploaded scene's triangles are grouped for the two-stage kernel's conservative test: out[0] pairs that

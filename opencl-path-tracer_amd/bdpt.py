@@ -108,6 +108,8 @@ lib.bdpt_set_launch_chunks.argtypes = [_vp, C.c_int]
 lib.bdpt_last_launch_chunks.argtypes = [_vp]
 lib.bdpt_two_stage_record_counts.argtypes = [_vp, C.POINTER(C.c_int)]
 lib.bdpt_set_order_scratch_limit.argtypes = [_vp, C.c_size_t]
+lib.bdpt_set_slice_wait_limit.argtypes = [_vp, C.c_double]
+lib.bdpt_last_launch_order_table.argtypes = [_vp]
 lib.bdpt_set_stream.argtypes = [_vp, _vp]
 lib.bdpt_use_default_stream.argtypes = [_vp]
 lib.bdpt_bind_accum.argtypes = [_vp, _vp]
@@ -449,14 +451,33 @@ class Context:
         self._check(lib.bdpt_set_sample_offset(self._h, first_sample))
 
     def set_stream(self, stream_ptr):
-        """Render on the HIP stream with this handle; 0 is HIP's default stream (torch's default stream)."""
-        if not stream_ptr:
-            self._check(lib.bdpt_use_default_stream(self._h))
-        else:
-            self._check(lib.bdpt_set_stream(self._h, stream_ptr))
+        """bdpt_set_stream, with its meaning of a null handle: render on the HIP stream with this handle, 0 / None = the
+        context's own stream."""
+        self._check(lib.bdpt_set_stream(self._h, stream_ptr or None))
+
+    def use_default_stream(self):
+        """bdpt_use_default_stream: render on HIP's default stream (handle 0)."""
+        self._check(lib.bdpt_use_default_stream(self._h))
 
     def use_own_stream(self):
         self._check(lib.bdpt_set_stream(self._h, None))
+
+    def follow_stream(self, stream_ptr):
+        """Render on the stream a caller's other work runs on, given as the handle torch reports
+        (torch.cuda.current_stream().cuda_stream): a non-zero handle is that stream, and 0 -- which is how torch names
+        HIP's default stream, and which bdpt_set_stream would read as "the context's own" -- selects the default stream."""
+        if stream_ptr:
+            self.set_stream(stream_ptr)
+        else:
+            self.use_default_stream()
+
+    def set_slice_wait_limit(self, seconds):
+        """Longest wait of a workgroup of a sliced launch for the run before it (0: derived from the expected launch time)."""
+        self._check(lib.bdpt_set_slice_wait_limit(self._h, seconds))
+
+    def last_launch_order_table(self):
+        """1 if the last launch took its class order from the table, 0 if it worked the order out as it went."""
+        return lib.bdpt_last_launch_order_table(self._h)
 
     def clear_accum(self):
         self.write_accum(np.zeros((self.height, self.width, 4), np.float32))

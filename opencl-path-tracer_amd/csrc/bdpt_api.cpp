@@ -75,7 +75,13 @@ struct bdpt_ctx {
     size_t order_scratch_limit = BDPT_ORDER_SCRATCH_DEFAULT;   /* bdpt_set_order_scratch_limit */
     int slice_tiles = 0;               /* tiles d_slice_sync has room for */
     int launch_chunks = 0;             /* bdpt_set_launch_chunks: 0 = chosen per launch */
-    bool sliced_unchecked = false;     /* a sliced launch was issued and its give-up mark has not been read yet */
+    /* One word of pinned host memory that a workgroup of a sliced launch sets when it gives up waiting for the run
+     * before it (slice_begin); sticky across launches until the host has reported it.  Read directly, after any wait
+     * for the stream, so every way of waiting sees it. */
+    uint32_t *h_slice_abort = nullptr, *d_slice_abort = nullptr;
+    double slice_wait_s = 0.0;         /* bdpt_set_slice_wait_limit: 0 = derived from the expected launch time */
+    double steady_ticks_per_ms = 1.0e5; /* the device's steady counter (wall_clock64): 100 MHz unless the device says otherwise */
+    int last_order_table = 0;          /* the last launch took its class order from the table (1) or worked it out as it went (0) */
     double ms_per_pixel_sample = 0.0;  /* measured on an earlier launch of this scene and these parameters; 0 = not yet */
     double last_launch_work = 0.0;     /* pixels x samples of the last launch, until its time has been read */
 
@@ -130,6 +136,19 @@ static hipError_t dev_upload(T *&dst, const std::vector<T> &src)
 }
 
 static clm_f3 v3(const float *p) { return clm_make3(p[0], p[1], p[2]); }
+
+/* After the host has waited for the context's stream (or for the end event of its last launch): did a workgroup of a
+ * sliced launch give up (slice_begin in bdpt_kernels.hip)?  Its tile and every later run of the launch were left
+ * undone, so the image is incomplete.  Reported once; the mark is then cleared so that the caller can reset
+ * (bdpt_set_camera) and render again. */
+static int check_sliced(bdpt_ctx *ctx, const char *who)
+{
+    if (!ctx->h_slice_abort || *(volatile uint32_t *)ctx->h_slice_abort == 0u) return BDPT_OK;
+    *(volatile uint32_t *)ctx->h_slice_abort = 0u;
+    return fail(ctx, BDPT_ERR_HIP, std::string(who) + ": a sliced launch did not complete in order (a workgroup waited longer than the limit "
+                                   "for the run before it and the launch was abandoned); the image, the seeds and the parity buffers are "
+                                   "incomplete -- reset with bdpt_set_camera and render again (bdpt_set_launch_chunks(ctx, 1) renders unsliced)");
+}
 
 int bdpt_ctx_device(const bdpt_ctx *ctx) { return ctx->device; }
 hipStream_t bdpt_ctx_stream(const bdpt_ctx *ctx) { return ctx->stream; }
@@ -212,6 +231,14 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if ((e = hipMalloc((void **)&ctx->d_slice_sync, slice_bytes)) != hipSuccess) return bail(e, "hipMalloc slice words");
     if ((e = hipMemset(ctx->d_slice_sync, 0, slice_bytes)) != hipSuccess) return bail(e, "hipMemset slice words");
     if ((e = hipMalloc((void **)&ctx->d_slice_cursor, npix * sizeof(uint4))) != hipSuccess) return bail(e, "hipMalloc slice cursors");
+    if ((e = hipHostMalloc((void **)&ctx->h_slice_abort, sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc give-up mark");
+    *ctx->h_slice_abort = 0u;
+    if ((e = hipHostGetDevicePointer((void **)&ctx->d_slice_abort, ctx->h_slice_abort, 0)) != hipSuccess) return bail(e, "hipHostGetDevicePointer");
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_ordinal) == hipSuccess && khz > 0) ctx->steady_ticks_per_ms = (double)khz;
+        else (void)hipGetLastError();
+    }
     *out = ctx;
     return BDPT_OK;
 }
@@ -227,6 +254,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
     dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters); dev_free(ctx->d_slice_sync); dev_free(ctx->d_slice_cursor);
     dev_free(ctx->d_class_masks);
+    if (ctx->h_slice_abort) (void)hipHostFree(ctx->h_slice_abort);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -334,6 +362,17 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         if (planes[i].surface >= (uint32_t)n_surfaces) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: plane surface id out of range");
     for (int i = 0; i < n_triangles; i++)
         if (triangles[i].surface >= (uint32_t)n_surfaces) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: triangle surface id out of range");
+    /* The reference's dot, distance and length work on all four components (kernel0.cl:331, :336, :398, :714); its own
+     * scene has w = 0 in every position, direction and normal (main.cpp:282-394), and so three-component arithmetic
+     * gives its results exactly.  With any other w (homogeneous w = 1, say) the reference computes something else --
+     * a sphere's |o - c|^2 grows by w^2 -- which this library does not reproduce: refuse instead of rendering another
+     * image silently.  -0.0f counts as zero. */
+    for (int i = 0; i < n_spheres; i++)
+        if (spheres[i].center[3] != 0.0f) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: sphere " + std::to_string(i) + " has center[3] != 0; the fourth component of positions, normals and directions must be 0");
+    for (int i = 0; i < n_planes; i++)
+        if (planes[i].normal[3] != 0.0f || planes[i].point[3] != 0.0f) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: plane " + std::to_string(i) + " has normal[3] or point[3] != 0; the fourth component of positions, normals and directions must be 0");
+    for (int i = 0; i < n_triangles; i++)
+        if (triangles[i].p0[3] != 0.0f || triangles[i].p1[3] != 0.0f || triangles[i].p2[3] != 0.0f) return fail(ctx, BDPT_ERR_INVALID, "bdpt_upload_scene: triangle " + std::to_string(i) + " has a vertex with [3] != 0; the fourth component of positions, normals and directions must be 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -625,12 +664,16 @@ int bdpt_read_seeds(bdpt_ctx *ctx, uint32_t *seeds)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) ctx->seeds[((size_t)x * H + y) * 4 + 3] = w[(size_t)y * W + x];
     std::memcpy(seeds, ctx->seeds.data(), npix * 4 * sizeof(uint32_t));
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_read_seeds");
 }
 
 int bdpt_set_camera(bdpt_ctx *ctx, const bdpt_camera *cam)
 {
     if (!ctx || !cam) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_camera: null argument");
+    /* as for the scene: the reference normalises the ray direction over four components (kernel0.cl:215) and its
+     * camera vectors have w = 0 (camera.cpp:137-139) */
+    if (cam->pos[3] != 0.0f || cam->look_at[3] != 0.0f || cam->up[3] != 0.0f)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_camera: pos[3], look_at[3] and up[3] must be 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->camera = *cam;
@@ -745,6 +788,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.counters = ctx->d_counters;
     K.slice_sync = ctx->d_slice_sync;
     K.slice_cursor = ctx->d_slice_cursor;
+    K.slice_abort = ctx->d_slice_abort;
     K.n_tiles = ctx->slice_tiles;                                       /* room; the launcher puts the launch's count here */
     K.n_chunks = 1;
     K.chunk_spp = spp;
@@ -820,6 +864,8 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     int rc = fill_kargs(ctx, spp, K);
     if (rc != BDPT_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    /* a launch that was abandoned since the host last looked: do not build on its image */
+    if ((rc = check_sliced(ctx, "bdpt_render")) != BDPT_OK) return rc;
     /* how long a sample of this scene takes, from the last launch if it has ended (no waiting; a stream under
      * capture is left alone) */
     if (ctx->have_launch && ctx->last_launch_work > 0.0) {
@@ -877,14 +923,30 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
                     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          /* an earlier launch may still read the old table */
                     dev_free(ctx->d_class_masks);
                     ctx->class_mask_bytes = 0;
-                    if (hipMalloc((void **)&ctx->d_class_masks, bytes) == hipSuccess) ctx->class_mask_bytes = bytes;
+                    /* not more than half of what is free now: other contexts and ranks on this GPU want memory too */
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = 0; (void)hipGetLastError(); }
+                    if (bytes <= free_b / 2 && hipMalloc((void **)&ctx->d_class_masks, bytes) == hipSuccess) ctx->class_mask_bytes = bytes;
                     else { ctx->d_class_masks = nullptr; (void)hipGetLastError(); }
                 }
             }
             if (bytes <= ctx->class_mask_bytes) { K.class_masks = ctx->d_class_masks; K.mask_words = (int)words; }
         }
     }
-    if (K.n_chunks > 1) ctx->sliced_unchecked = true;
+    ctx->last_order_table = K.class_masks ? 1 : 0;
+    /* How long a workgroup of a sliced launch may wait for the run before it.  A legitimate wait is at most one run
+     * of one tile plus scheduling, far below the duration of the whole launch; the limit is a hundred times the
+     * expected duration of the launch (from the measured time per sample when there is one, else from a generous
+     * 1e-5 ms per pixel-sample and triangle), at least a minute. */
+    {
+        double wait_ms = ctx->slice_wait_s * 1e3;
+        if (!(ctx->slice_wait_s > 0.0)) {
+            const double work = (double)K.rw * K.rh / std::max(1, K.tile_stride) * spp;
+            const double per = ctx->ms_per_pixel_sample > 0.0 ? ctx->ms_per_pixel_sample : 1.0e-5 * (1.0 + K.scene.n_triangles);
+            wait_ms = std::max(60.0e3, 100.0 * work * per);
+        }
+        K.slice_wait_ticks = (unsigned long long)std::min(1.0e18, wait_ms * ctx->steady_ticks_per_ms);
+    }
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     if (ctx->params.integrator == BDPT_INTEGRATOR_PATH_TRACE) {
@@ -908,14 +970,7 @@ int bdpt_sync(bdpt_ctx *ctx)
     if (!ctx) return BDPT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->sliced_unchecked) {
-        /* a workgroup of a sliced launch that stopped waiting for the run before it leaves a mark (slice_begin) */
-        uint32_t gave_up = 0;
-        HIP_TRY(ctx, hipMemcpy(&gave_up, ctx->d_slice_sync + 1, sizeof gave_up, hipMemcpyDeviceToHost));
-        ctx->sliced_unchecked = false;
-        if (gave_up) return fail(ctx, BDPT_ERR_HIP, "bdpt_sync: a sliced launch did not complete in order; the image is invalid");
-    }
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_sync");
 }
 
 int bdpt_render(bdpt_ctx *ctx, int spp)
@@ -932,6 +987,16 @@ int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks)
     ctx->launch_chunks = chunks;
     return BDPT_OK;
 }
+
+int bdpt_set_slice_wait_limit(bdpt_ctx *ctx, double seconds)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    if (!(seconds >= 0.0) || seconds > 1.0e6) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_slice_wait_limit: 0 (automatic) to 1e6 seconds");
+    ctx->slice_wait_s = seconds;
+    return BDPT_OK;
+}
+
+int bdpt_last_launch_order_table(const bdpt_ctx *ctx) { return ctx ? ctx->last_order_table : 0; }
 
 int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes)
 {
@@ -963,7 +1028,7 @@ int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
     HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_last_launch_ms");
 }
 
 int bdpt_read_accum(bdpt_ctx *ctx, float *rgba)
@@ -972,7 +1037,7 @@ int bdpt_read_accum(bdpt_ctx *ctx, float *rgba)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(rgba, ctx->d_accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_read_accum");
 }
 
 int bdpt_write_accum(bdpt_ctx *ctx, const float *rgba)
@@ -1002,7 +1067,7 @@ int bdpt_read_aov(bdpt_ctx *ctx, int kind, void *out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_read_aov");
 }
 
 int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[BDPT_N_COUNTERS])
@@ -1013,7 +1078,7 @@ int bdpt_read_counters(bdpt_ctx *ctx, uint64_t out[BDPT_N_COUNTERS])
     unsigned long long c[BDPT_N_COUNTERS];
     HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     for (int i = 0; i < BDPT_N_COUNTERS; i++) out[i] = c[i];
-    return BDPT_OK;
+    return check_sliced(ctx, "bdpt_read_counters");
 }
 
 int bdpt_query_rays(bdpt_ctx *ctx, const float *rays, const int32_t *origin_ids, int n, int32_t *out_ids, float *out_pos,

@@ -51,17 +51,28 @@ struct Slice {
     int run;
     int s0, s1;             /* the samples s0 <= s < s1 of the launch's order, for every pixel of the tile */
     bool shared;            /* the launch is sliced: pixel state written here is read by another workgroup of this launch */
+    bool abandoned;         /* the run before this one never completed: this workgroup must touch nothing (see slice_begin) */
 };
 
 typedef __attribute__((address_space(1))) uint32_t slice_u32;
 typedef __attribute__((address_space(1))) unsigned long long slice_u64;
 #define BDPT_SLICE_HEADER 4                 /* words in front of the per-tile words: ticket counter, give-up mark, padding */
-#define BDPT_SLICE_SPIN_LIMIT (1u << 24)    /* polls (about a microsecond apart) before a workgroup gives up on the run before it */
 
+/*
+ * Waiting for the run before.  The holder of ticket t - n_tiles is resident (it has drawn its ticket) and waits only
+ * for lower tickets, so the wait ends.  The guard against a fault elsewhere is a limit in wall-clock time that the host
+ * derives from how long the launch is expected to take (K.slice_wait_ticks, steady-counter ticks): a workgroup that
+ * waits longer gives up.  It then raises the launch's give-up mark (slice_sync[1], which every waiting workgroup also
+ * watches, so the rest of the launch drains at once) and the context's sticky mark in host memory (K.slice_abort, which
+ * the host checks whenever it has waited for the stream), and ends WITHOUT loading, tracing or storing anything: state
+ * that is not ready is never read and nothing stale is written over the tile.  The image is then incomplete, and the
+ * host says so; it is never silently wrong.
+ */
 BDPT_DEV Slice slice_begin(const bdpt_kargs &K)
 {
     Slice sl;
     sl.shared = K.n_chunks > 1;
+    sl.abandoned = false;
     if (!sl.shared) {
         sl.tile = (int)(blockIdx.y * gridDim.x + blockIdx.x);
         sl.run = 0;
@@ -69,18 +80,22 @@ BDPT_DEV Slice slice_begin(const bdpt_kargs &K)
         sl.s1 = K.spp;
         return sl;
     }
-    __shared__ uint32_t ticket;
+    __shared__ uint32_t ticket, gave_up;
     if (threadIdx.x == 0) {
         slice_u32 *sync = (slice_u32 *)(uintptr_t)K.slice_sync;
         const uint32_t t = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t run = t / (uint32_t)K.n_tiles, tile = t % (uint32_t)K.n_tiles;
-        /* The holder of ticket t - n_tiles is resident (it has drawn its ticket) and waits only for lower tickets, so
-         * this ends; the limit is a guard against a fault elsewhere, and the host reports a launch that hit it. */
-        uint32_t polls = 0;
+        uint32_t polls = 0, stop = 0;
+        const unsigned long long t_begin = wall_clock64();
         while (__hip_atomic_load(sync + BDPT_SLICE_HEADER + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < run) {
-            if (++polls > BDPT_SLICE_SPIN_LIMIT) {
-                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+            if ((++polls & 63u) == 0u) {                    /* every 64 polls, some 100 microseconds: the mark and the clock */
+                if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { stop = 1u; break; }
+                if (wall_clock64() - t_begin > K.slice_wait_ticks) {
+                    __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(K.slice_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    stop = 1u;
+                    break;
+                }
             }
             __builtin_amdgcn_s_sleep(32);
         }
@@ -89,9 +104,11 @@ BDPT_DEV Slice slice_begin(const bdpt_kargs &K)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ticket = t;
+        gave_up = stop;
     }
     __syncthreads();
     const uint32_t t = ticket;
+    sl.abandoned = gave_up != 0u;
     sl.tile = (int)(t % (uint32_t)K.n_tiles);
     sl.run = (int)(t / (uint32_t)K.n_tiles);
     sl.s0 = sl.run * K.chunk_spp;
@@ -779,6 +796,7 @@ void bdpt_direct_kernel(const bdpt_kargs K)
     if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
     if (MODE == MODE_LDS2) lds_fill_scene<true>(K.scene);
     const Slice sl = slice_begin(K);
+    if (sl.abandoned) return;                               /* the whole workgroup: nothing read, nothing written */
     int x, y;
     lane_pixel(K, sl.tile, x, y);
     if (x < K.rx0 + K.rw && y < K.ry0 + K.rh)
@@ -972,40 +990,6 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         r1 = S.tri_bound[base + 64 < total_f4 ? base + 64 : 0];
         r2 = S.tri_bound[base + 128 < total_f4 ? base + 128 : 0];
     };
-#ifdef BDPT_TILED_SCALAR
-    if (active) {
-        const int count = S.n_triangles;
-        if (COUNT) *n_cull += (unsigned long long)count;
-        auto excess = [&](float4 s) {
-            const float u = __builtin_fmaf(s.z, d.z, __builtin_fmaf(s.y, d.y, __builtin_fmaf(s.x, d.x, -od)));
-            const float t = __builtin_fmaf(s.z, o2.z, __builtin_fmaf(s.y, o2.y, __builtin_fmaf(s.x, o2.x, s.w)));
-            return __builtin_fmaf(-u, u, t);
-        };
-        auto full = [&](int i, bool wanted) {
-            if (__builtin_amdgcn_ballot_w64(wanted) == 0) return;
-            const size_t r = (size_t)i * BDPT_TRI_F4;
-            const float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2),
-                         q3 = uload(S.tri, r + 3), q4 = uload(S.tri, r + 4);
-            const float e2z = uload(S.tri, r + 5).x;
-            if (wanted) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
-            if (COUNT && wanted) ++*n_exact;
-        };
-        int j = 0;
-        for (; j + 4 <= count; j += 4) {
-            const float4 s0 = uload(S.tri_bound, j), s1 = uload(S.tri_bound, j + 1), s2 = uload(S.tri_bound, j + 2), s3 = uload(S.tri_bound, j + 3);
-            const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3);
-            const float least = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
-            if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
-                full(j, !(e0 > bound));
-                full(j + 1, !(e1 > bound));
-                full(j + 2, !(e2 > bound));
-                full(j + 3, !(e3 > bound));
-            }
-        }
-        for (; j < count; j++) full(j, !(excess(uload(S.tri_bound, j)) > bound));
-    }
-    return finish_hit(S, b, d);
-#endif
     if (n_tiles > 0) fetch(0);
     for (int tile = 0; tile < n_tiles; tile++) {
         float4 *buf = wave_lds + (tile & 1) * BDPT_TILE_F4;
@@ -1049,17 +1033,8 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
                 }
             }
             for (; j + 4 <= count; j += 4) {
-#if defined(BDPT_DBG_NOLDS)
-                float4 s0 = buf[j & 3], s1 = buf[(j & 3) + 1], s2 = buf[(j & 3) + 2], s3 = buf[(j & 3) + 3];
-                asm volatile("" : "+v"(s0.x), "+v"(s1.x), "+v"(s2.x), "+v"(s3.x));
-#else
                 const float4 s0 = buf[j], s1 = buf[j + 1], s2 = buf[j + 2], s3 = buf[j + 3];
-#endif
-#if defined(BDPT_DBG_NOVALU)
-                const float e0 = s0.x + s0.w + s0.y + s0.z, e1 = s1.x + s1.w + s1.y + s1.z, e2 = s2.x + s2.w + s2.y + s2.z, e3 = s3.x + s3.w + s3.y + s3.z;
-#else
                 const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3);
-#endif
                 /* one compare for the four: no input here is a NaN (upload replaces what could make one by -inf) */
                 const float least = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
                 if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
@@ -1190,6 +1165,7 @@ void bdpt_tiled_kernel(const bdpt_kargs K)
 {
     float4 *wave_lds = bdpt_lds + (threadIdx.x >> 6) * (2 * BDPT_TILE_F4);   /* dynamic LDS: two tile buffers per wavefront */
     const Slice sl = slice_begin(K);
+    if (sl.abandoned) return;
     int x, y;
     lane_pixel(K, sl.tile, x, y);
     const bool inside = x < K.rx0 + K.rw && y < K.ry0 + K.rh;             /* lanes outside still help copy tiles */
@@ -1446,7 +1422,7 @@ static hipError_t sliced_grid(bdpt_kargs &K, dim3 &grid, hipStream_t stream)
     const long long tiles = (long long)grid.x * grid.y, room = K.n_tiles;
     K.wg_x = (int)grid.x;
     K.n_tiles = (int)tiles;
-    if (K.n_chunks > 1 && (tiles > room || tiles * K.n_chunks > 0x7fffffffLL || !K.slice_sync || !K.slice_cursor)) K.n_chunks = 1;
+    if (K.n_chunks > 1 && (tiles > room || tiles * K.n_chunks > 0x7fffffffLL || !K.slice_sync || !K.slice_cursor || !K.slice_abort)) K.n_chunks = 1;
     if (K.n_chunks <= 1 || tiles == 0) { K.n_chunks = 1; K.chunk_spp = K.spp; return hipSuccess; }
     grid = dim3((unsigned)(tiles * K.n_chunks));
     /* ticket counter, give-up mark and the tiles' words; the allocation is padded so that whole 16-byte units can be cleared */

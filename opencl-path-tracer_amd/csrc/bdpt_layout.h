@@ -102,11 +102,15 @@ struct bdpt_kargs {
      * tile_stride <= 1: the whole region.  tile_w is a multiple of 16 (a workgroup is 8 or 16 pixels wide), tile_h of 8. */
     int tile_w, tile_h, tiles_x, tile_stride, tile_phase;
     /* Sliced launch (see slice_begin in bdpt_kernels.hip): n_chunks > 1 starts n_chunks workgroups per tile, each
-     * running chunk_spp samples.  slice_sync[0] is the ticket counter, slice_sync[1 + t] the number of runs of tile
-     * t that are complete; both zero when the launch starts.  slice_cursor keeps a pixel's sample cursor between
+     * running chunk_spp samples.  slice_sync[0] is the ticket counter, slice_sync[1] the launch's give-up mark, slice_sync[4 + t] the
+     * number of runs of tile t that are complete; all zero when the launch starts.  slice_cursor keeps a pixel's sample cursor between
      * runs.  n_tiles = workgroups of the unsliced grid, wg_x of them per row of the region. */
     uint32_t *slice_sync;
     uint4 *slice_cursor;
+    /* slice_abort: one word of host memory the device can write (the context's sticky "a sliced launch gave up" mark);
+     * slice_wait_ticks: how long, in ticks of the device's steady counter, a workgroup waits for the run before it */
+    uint32_t *slice_abort;
+    unsigned long long slice_wait_ticks;
     /* Class order from a table (cursor_fill_masks in bdpt_kernels.hip): word w of class c of pixel p, at
      * ((c - 1) * mask_words + w) * width * height + p, has bit b set when sample 32 w + b of the launch is of class c.
      * Null: the classes are worked out again for every class (cursor_rounds in bdpt_device.h). */

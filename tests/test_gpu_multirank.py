@@ -34,7 +34,7 @@ def _worker(rank, world, port, mode, out_path):
         ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED))
         ctx.set_camera(scene.camera)
         ctx.bind_accum(image.data_ptr())
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.follow_stream(torch.cuda.current_stream().cuda_stream)
         if mode == "samples":
             dr.render_sample_split(ctx, SPP, world, rank, wait=False)
             img = dr.combine_sample_split(image, SPP, dist)

@@ -731,8 +731,28 @@ def test_error_paths(bdpt):
     bad.triangles["surface"][3] = 99
     with pytest.raises(bdpt.BdptError):
         ctx.upload_scene(bad)
+    # a fourth component other than 0 (homogeneous w = 1) would change the reference's four-component dot and
+    # distance (kernel0.cl:331, :336, :398): refused, not dropped
+    for arr, field in (("spheres", "center"), ("triangles", "p0"), ("triangles", "p1"), ("triangles", "p2")):
+        bad = bdpt.Scene.cornell()
+        getattr(bad, arr)[field][1, 3] = 1.0
+        with pytest.raises(bdpt.BdptError, match="fourth component"):
+            ctx.upload_scene(bad)
+    for field in ("normal", "point"):
+        bad = bdpt.Scene.cornell_planes()
+        bad.planes[field][0, 3] = 1.0
+        with pytest.raises(bdpt.BdptError, match="fourth component"):
+            ctx.upload_scene(bad)
+    ok = bdpt.Scene.cornell()
+    ok.spheres["center"][:, 3] = -0.0
+    ctx.upload_scene(ok)
     ctx.upload_scene(scene)
     ctx.upload_seeds(bdpt.make_seeds(16, 16))
+    for field in ("pos", "look_at", "up"):
+        cam = scene.camera.copy()
+        cam[field][3] = 1.0
+        with pytest.raises(bdpt.BdptError, match="must be 0"):
+            ctx.set_camera(cam)
     ctx.set_camera(scene.camera)
     with pytest.raises(bdpt.BdptError):
         ctx.render(0)

@@ -190,3 +190,49 @@ def test_class_order_from_the_table_is_the_order_worked_out_on_the_fly(bdpt, var
     p = bdpt.default_params(kernel_variant=variant, **MODES[order])
     words_32 = W * H * p.max_light_bounces * 4
     _same(_render(bdpt, scene, p, 2, (32, 33), order_scratch=words_32), _render(bdpt, scene, p, 2, (32, 33), order_scratch=0), "limit between two launches")
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+def test_a_launch_that_gives_up_is_reported_on_every_way_of_waiting_and_leaves_nothing_stale(bdpt, variant):
+    """With a wait limit of a nanosecond every workgroup that has to wait for the run before it gives up: the launch is
+    abandoned (later runs drain without touching the image), and whichever call next waits for it -- bdpt_sync,
+    bdpt_read_accum, bdpt_last_launch_ms after bdpt_render_async, or the next bdpt_render_async itself -- says so,
+    once.  After a reset the context renders what a fresh context renders."""
+    scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()
+    p = bdpt.default_params(kernel_variant=variant, **MODES["stream_mean"])
+    w, h = 512, 256
+    with bdpt.Context(w, h) as ctx:
+        ctx.set_params(p)
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
+        ctx.set_camera(scene.camera)
+        ctx.set_launch_chunks(1)
+        ctx.render(24)
+        want = ctx.read_accum()
+        ctx.set_launch_chunks(8)
+        for waiter in ("sync", "read_accum", "last_launch_ms", "render_async"):
+            ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
+            ctx.set_camera(scene.camera)
+            ctx.set_slice_wait_limit(1e-9)
+            ctx.render_async(24)
+            assert ctx.last_launch_chunks() == 8
+            with pytest.raises(bdpt.BdptError, match="did not complete in order"):
+                if waiter == "sync":
+                    ctx.sync()
+                elif waiter == "read_accum":
+                    ctx.read_accum()
+                elif waiter == "last_launch_ms":
+                    ctx.last_launch_ms()
+                else:
+                    import time
+                    time.sleep(1.0)                     # nothing waits: the mark is simply there when the next launch is asked for
+                    ctx.render_async(1)
+            ctx.sync()                                  # reported once
+            # the abandoned image holds only whole runs of whole tiles: every pixel is untouched or a sum that a run left
+            ctx.set_slice_wait_limit(0)
+            ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
+            ctx.set_camera(scene.camera)
+            ctx.render(24)
+            assert ctx.read_accum().tobytes() == want.tobytes(), waiter
+        with pytest.raises(bdpt.BdptError):
+            ctx.set_slice_wait_limit(-1.0)

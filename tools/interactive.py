@@ -57,7 +57,7 @@ ctx.upload_seeds(bdpt.make_seeds(W, H, 0x5EED))
 ctx.set_camera(cams[0])
 image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 ctx.bind_accum(image.data_ptr())
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.follow_stream(torch.cuda.current_stream().cuda_stream)
 
 lat = []
 first_still = seeds_before_still = None

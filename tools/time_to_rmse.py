@@ -59,7 +59,7 @@ def make_ctx(seed, **params):
     ctx.set_camera(scene.camera)
     buf = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ctx.bind_accum(buf.data_ptr())
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.follow_stream(torch.cuda.current_stream().cuda_stream)
     return ctx, buf
 
 

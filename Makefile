@@ -17,7 +17,7 @@ ORACLE   := oracle/libbdpt_oracle.so
 ORACLE_NOFMA := oracle/libbdpt_oracle_nofma.so
 
 LIB_SRCS := $(CSRC)/bdpt_api.cpp $(CSRC)/bdpt_group.cpp $(CSRC)/bdpt_kernels.hip
-LIB_DEPS := $(LIB_SRCS) $(wildcard $(CSRC)/*.h) include/bdpt.h include/bdpt_clmath.h
+LIB_DEPS := $(LIB_SRCS) $(wildcard $(CSRC)/*.h) include/bdpt.h include/bdpt_clmath.h $(CSRC)/bdpt_slice_probe.hip tools/check_slice_isa.py
 
 HOSTLIB  := $(PKG)/libbdpt_host.so
 HOST_SRCS := $(PKG)/host/camera.cpp $(PKG)/host/scenes.cpp $(PKG)/host/renderer.cpp $(PKG)/host/scene_io.cpp $(PKG)/host/image_io.cpp $(PKG)/host/capi.cpp
@@ -34,7 +34,10 @@ $(HOSTLIB): $(HOST_DEPS) $(LIB)
 $(HOSTBIN): $(PKG)/host/main.cpp $(HOSTLIB)
 	$(CXX) $(CXXFLAGS) $(PKG)/host/main.cpp -o $@ -L$(PKG) -lbdpt_host -lbdpt_amd -Wl,-rpath,'$$ORIGIN'
 
+# the library is built only if the sliced-launch hand-off (csrc/bdpt_slice.h) compiles to the store, wait and
+# invalidate instructions its correctness rests on
 $(LIB): $(LIB_DEPS)
+	python3 tools/check_slice_isa.py
 	$(HIPCC) $(HIPFLAGS) -shared -x hip $(LIB_SRCS) -o $@ -ldl
 
 # -mfma: fmaf() becomes one instruction; the no-FMA build calls libm's fmaf(),

@@ -69,3 +69,29 @@ def test_without_a_gpu_create_fails_loudly(bdpt):
     else:
         ctx.close()
         pytest.skip("a GPU is present")
+
+
+def test_sliced_launch_hand_off_compiles_to_the_instructions_it_depends_on():
+    """The run-to-run hand-off of sliced launches (csrc/bdpt_slice.h) is correct because of which store and load
+    instructions it compiles to; tools/check_slice_isa.py compiles the probe for gfx950 (no GPU needed) and reads
+    them.  The checker itself is checked on doctored assembly: a state store whose sc1 bit became nt, a plain store,
+    a missing invalidate."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc is not on PATH")
+    spec = importlib.util.spec_from_file_location("check_slice_isa", os.path.join(ROOT, "tools", "check_slice_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "probe.s")
+        subprocess.run(["hipcc"] + chk.FLAGS + ["--cuda-device-only", "-S", "-o", out, chk.PROBE], check=True, capture_output=True)
+        asm = open(out).read()
+    assert chk.check(asm) == []
+    assert chk.check(re.sub(r"(global_store_dwordx2 [^\n]*) sc1", r"\1 nt", asm, count=1))
+    assert chk.check(re.sub(r"(global_store_dword [^\n]*) sc1", r"\1", asm, count=1))
+    assert chk.check(asm.replace("buffer_inv sc1", "s_nop 0"))
+    assert chk.check(asm.replace("s_waitcnt vmcnt(0)", "s_nop 0"))

@@ -207,14 +207,14 @@ def test_a_launch_that_gives_up_is_reported_on_every_way_of_waiting_and_leaves_n
         ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
         ctx.set_camera(scene.camera)
         ctx.set_launch_chunks(1)
-        ctx.render(24)
+        ctx.render(160)
         want = ctx.read_accum()
         ctx.set_launch_chunks(8)
         for waiter in ("sync", "read_accum", "last_launch_ms", "render_async"):
             ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
             ctx.set_camera(scene.camera)
             ctx.set_slice_wait_limit(1e-9)
-            ctx.render_async(24)
+            ctx.render_async(160)
             assert ctx.last_launch_chunks() == 8
             with pytest.raises(bdpt.BdptError, match="did not complete in order"):
                 if waiter == "sync":
@@ -232,7 +232,7 @@ def test_a_launch_that_gives_up_is_reported_on_every_way_of_waiting_and_leaves_n
             ctx.set_slice_wait_limit(0)
             ctx.upload_seeds(bdpt.make_seeds(w, h, 4242))
             ctx.set_camera(scene.camera)
-            ctx.render(24)
+            ctx.render(160)
             assert ctx.read_accum().tobytes() == want.tobytes(), waiter
         with pytest.raises(bdpt.BdptError):
             ctx.set_slice_wait_limit(-1.0)

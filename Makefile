@@ -25,7 +25,13 @@ HOST_DEPS := $(HOST_SRCS) $(PKG)/host/bdpt_host.h include/bdpt.h
 CXX      ?= g++
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall
 
-all: $(LIB) $(HOSTLIB) $(HOSTBIN) $(ORACLE) $(ORACLE_NOFMA)
+CLBASE   := tools/cl_baseline
+
+all: $(LIB) $(HOSTLIB) $(HOSTBIN) $(ORACLE) $(ORACLE_NOFMA) $(CLBASE)
+
+# harness for the reference's own kernel on a CPU OpenCL device (a reported baseline; needs only the OpenCL loader)
+$(CLBASE): tools/cl_baseline.c
+	$(CC) -O2 -std=c99 -Wall tools/cl_baseline.c -o $@ -lOpenCL
 
 # host-side renderer surface (C++), linked against the C-ABI library beside it
 $(HOSTLIB): $(HOST_DEPS) $(LIB)
@@ -49,6 +55,6 @@ $(ORACLE_NOFMA): oracle/bdpt_oracle.c oracle/bdpt_oracle.h include/bdpt.h includ
 	$(CC) $(ORCFLAGS) oracle/bdpt_oracle.c -o $@ -lm
 
 clean:
-	rm -f $(LIB) $(HOSTLIB) $(ORACLE) $(ORACLE_NOFMA) $(HOSTBIN)
+	rm -f $(LIB) $(HOSTLIB) $(ORACLE) $(ORACLE_NOFMA) $(HOSTBIN) $(CLBASE)
 
 .PHONY: all clean

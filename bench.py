@@ -16,9 +16,15 @@ as N grows (weak scaling); value = all ranks' paths / max-over-ranks time.
 One path = one pixel-sample = one execution of the reference's
 bi_directional_path_trace (/root/reference/src/kernel/kernel0.cl:571-864).
 
+With N > 1 the weak-scaling steps are followed by as many strong-scaling steps:
+the samples of ONE GPU's step dealt to the N ranks (`strong_scaling` in the line).
+
 Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
-FP32 vector peak; `cpu_baseline` times the CPU oracle on this host's cores on a
-bounded sample of the same workload.
+FP32 vector peak; `time_to_rmse` (N = 1) is the wall time from a camera reset
+until the image is within RMSE 0.02 of a converged reference; `cpu_baseline`
+times the CPU oracle on this host's cores on a bounded sample of the same
+workload and, when this host has a CPU OpenCL device and the reference's kernel
+file, the reference's own kernel on it (tools/cl_baseline, a child process).
 """
 import argparse
 import json
@@ -47,29 +53,35 @@ def recorded(name, key):
         return None
 
 
-def cpu_opencl_status():
-    """Whether the reference's OpenCL kernel could be timed on this host: it needs a CPU OpenCL device (PoCL or the
-    like).  Returns a short reason string; this build has no harness for that route because no image it was developed
-    on has such a device."""
-    import ctypes
-    try:
-        cl = ctypes.CDLL("libOpenCL.so.1")
-    except OSError:
-        return "unavailable: no OpenCL loader on this host"
-    n = ctypes.c_uint(0)
-    if cl.clGetPlatformIDs(0, None, ctypes.byref(n)) != 0 or n.value == 0:
-        return "unavailable: no OpenCL platform"
-    plats = (ctypes.c_void_p * n.value)()
-    cl.clGetPlatformIDs(n.value, plats, None)
-    CL_DEVICE_TYPE_CPU = 1 << 1
-    cpus = 0
-    for p in plats:
-        m = ctypes.c_uint(0)
-        if cl.clGetDeviceIDs(ctypes.c_void_p(p), ctypes.c_ulong(CL_DEVICE_TYPE_CPU), 0, None, ctypes.byref(m)) == 0:
-            cpus += m.value
-    if cpus == 0:
-        return "unavailable: %d OpenCL platform(s), none with a CPU device" % n.value
-    return "not run: a CPU OpenCL device exists but this build has no harness for the reference kernel"
+def reference_on_cpu_opencl(scene, camera, seeds, width, height, frames=16, warmup=2, timeout_s=240):
+    """The reference's own kernel on a CPU OpenCL device of this host, through tools/cl_baseline run as a child process
+    (a fresh process: nothing of it shares this one's GPU state).  Returns (lines, reason): the harness's JSON lines, one
+    per build option, or an empty list and the reason it gave ("pocl baseline unavailable: ...")."""
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "cl_baseline")
+    if not os.path.exists(exe):
+        return [], "unavailable: tools/cl_baseline is not built"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cl_input
+    with tempfile.TemporaryDirectory() as tmp:
+        blob = os.path.join(tmp, "scene.bin")
+        cl_input.write(blob, scene, camera, seeds, width, height)
+        try:
+            r = subprocess.run([exe, "--input", blob, "--frames", str(frames), "--warmup", str(warmup)], capture_output=True, text=True,
+                               timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return [], "not finished within %d s" % timeout_s
+    lines = []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                lines.append(json.loads(ln))
+            except ValueError:
+                pass
+    if lines:
+        return lines, None
+    text = (r.stdout.strip() or r.stderr.strip() or "exit status %d" % r.returncode).splitlines()[-1]
+    return [], text.replace("pocl baseline unavailable: ", "unavailable: ")
 
 
 def start_ranks(n):
@@ -106,6 +118,11 @@ def main():
     ap.add_argument("--no-stream-line", action="store_true",
                     help="skip the extra launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the combined mean image of the last step (.npy)")
+    ap.add_argument("--dump-strong-image", default=None, help="N > 1: rank 0 saves the combined mean image of the last strong-scaling step (.npy)")
+    ap.add_argument("--no-time-to-rmse", action="store_true", help="skip the time-to-target-RMSE measurement (N = 1, c2)")
+    ap.add_argument("--rmse-target", type=float, default=0.02)
+    ap.add_argument("--rmse-ref-spp", type=int, default=16384)
+    ap.add_argument("--strong-spp", type=int, default=None, help="N > 1: total samples per pixel of the strong-scaling steps (default: --spp)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -205,6 +222,50 @@ def main():
 
     variant = ctx.last_launch_variant()
     variant_name = {1: "DIRECT", 3: "LDS", 4: "TILED", 5: "LDS2"}.get(variant, str(variant))
+    weak_chunks = ctx.last_launch_chunks()
+
+    # Strong scaling (N > 1): the SAME total work as one GPU's step -- `strong_spp` samples per pixel in all -- dealt to the
+    # ranks (rank r renders sample indices [r*S/N, (r+1)*S/N)), combined by the same reduce.  Start-up, table fill, reduce and
+    # rank skew weigh N times more against the render here than in the weak-scaling steps above.
+    strong = None
+    if world > 1:
+        strong_spp = args.strong_spp or SPP
+        s_launch, s_reduce, s_image = [], [], [None]
+
+        def strong_step(record):
+            dr.render_sample_split(ctx, strong_spp, world, rank, wait=False)
+            ev[0].record()
+            s_image[0] = dr.combine_sample_split(accum, strong_spp, dist)
+            ev[1].record()
+            if record:
+                s_launch.append(ctx.last_launch_ms() if dr.sample_range(strong_spp, world, rank)[1] > 0 else 0.0)
+                ev[1].synchronize()
+                s_reduce.append(ev[0].elapsed_time(ev[1]))
+
+        for _ in range(max(1, args.warmup)):
+            strong_step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            strong_step(True)
+        fence()
+        s_elapsed = time.perf_counter() - t0
+        t = torch.tensor([s_elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s_elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sum(s_launch) / len(s_launch))
+        strong = {
+            "total_spp": strong_spp, "spp_per_rank": [dr.sample_range(strong_spp, world, r)[1] for r in range(world)],
+            "ms_per_step": round(s_elapsed / args.steps * 1e3, 3),
+            "mpaths_per_s": round(W * H * strong_spp * args.steps / s_elapsed / 1e6, 2),
+            "per_rank_kernel_ms": [round(m, 3) for m in gathered],
+            "reduce_ms": round(sum(s_reduce) / len(s_reduce), 3),
+            "what": "fixed total work: one step renders total_spp samples per pixel in all, dealt to the ranks, one reduce; "
+                    "speed-up over one GPU = this mpaths_per_s / the N=1 line's value",
+        }
+        if rank == 0 and args.dump_strong_image:
+            np.save(args.dump_strong_image, s_image[0].cpu().numpy())
     paths_per_step = world * W * H * SPP
     value = paths_per_step * args.steps / elapsed / 1e6
     out = {
@@ -225,7 +286,7 @@ def main():
             "rng_mode": "strided", "accumulate": "sum", "sample_order": {"auto": "adaptive (roulette classes for pixels whose first eye ray reaches a surface)", "index": "index",
                              "class": "roulette class", "adaptive": "adaptive"}[args.order],
             "kernel_variant": variant_name,
-            "launch": "%d runs per workgroup tile (8x8 pixels), each a workgroup of its own (bdpt_set_launch_chunks: automatic)" % ctx.last_launch_chunks(),
+            "launch": "%d runs per workgroup tile (8x8 pixels), each a workgroup of its own (bdpt_set_launch_chunks: automatic)" % weak_chunks,
             "split": "samples per pixel" if world > 1 else "none",
             "combine": ("%s reduce(sum) of %dx%dx4 f32 to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (host tensors; rehearsal)", W, H)) if world > 1 else "none",
         },
@@ -233,6 +294,7 @@ def main():
     if world > 1:
         out["per_rank_kernel_ms"] = [round(m, 3) for m in per_rank_ms]
         out["reduce_ms"] = round(sum(reduce_ms) / len(reduce_ms), 3)     # rank 0: end of its launch -> combined image; includes waiting for the slowest rank
+        out["strong_scaling"] = strong
 
     if rank == 0 and args.dump_image:
         np.save(args.dump_image, image.cpu().numpy())
@@ -280,7 +342,7 @@ def main():
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
             "frac_reference_formulation": round(flops_ref / avg_s / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (ctx.last_launch_chunks() - 1),
+            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (weak_chunks - 1),
             "traffic_source": None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run"),
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "flops_per_launch_reference_formulation": flops_ref,
             "rays_traced": rays, "rays_reference_formulation": rays_ref, "paths_full": full, "paths_early": early,
@@ -312,6 +374,58 @@ def main():
                                   "what": "rng_mode STREAM + accum_mode MEAN: the reference's own generator and running mean, one launch"}
             ctx.set_params(bench_params)
 
+    # The second half of the headline metric: wall time from a camera reset until the accumulated image is within
+    # `rmse_target` (RMSE on linear RGB clamped to [0,1]) of a converged reference -- a `rmse_ref_spp` render of the
+    # reference's own sequence (STREAM + MEAN) with other seeds -- checked after every 64-sample launch.  Outside the
+    # timed steps.  The time includes the RMSE evaluation on the device after every launch.
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_time_to_rmse:
+        ctx.set_params(bench_params)
+        ctx.bind_accum(accum.data_ptr())
+        ctx.follow_stream(torch.cuda.current_stream().cuda_stream)
+        with bdpt.Context(W, H, device=local_rank) as rctx:
+            ref_buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            rctx.upload_scene(scene)
+            rctx.upload_seeds(bdpt.make_seeds(W, H, 0xBEEF))
+            rctx.set_camera(scene.camera)
+            rctx.bind_accum(ref_buf.data_ptr())
+            rctx.render(args.rmse_ref_spp)
+            ref = ref_buf[..., :3].clamp(0, 1).clone()
+        del ref_buf
+        chunk, max_spp = 64, 8192
+        total = torch.zeros_like(accum)
+        ctx.set_camera(scene.camera)
+        ctx.set_sample_offset(0)
+        ctx.render(chunk)                         # warm-up of this launch size and of the RMSE evaluation's device code
+        total += accum
+        torch.sqrt(torch.mean(((total[..., :3] / chunk).clamp(0, 1) - ref) ** 2)).item()
+        total.zero_()
+        ctx.set_camera(scene.camera)              # the reset the clock starts at
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done, hit, curve = 0, None, []
+        while done < max_spp:
+            ctx.set_sample_offset(done)
+            ctx.num_samples = 0
+            ctx.render_async(chunk)
+            done += chunk
+            total += accum
+            err = torch.sqrt(torch.mean(((total[..., :3] / done).clamp(0, 1) - ref) ** 2)).item()
+            t = time.perf_counter() - t0
+            curve.append([done, round(t * 1e3, 2), round(err, 5)])
+            if err < args.rmse_target:
+                hit = (done, t, err)
+                break
+        out["time_to_rmse"] = {
+            "seconds": None if hit is None else round(hit[1], 4), "spp_at_target": None if hit is None else hit[0],
+            "rmse_at_target": None if hit is None else round(hit[2], 5), "bound": args.rmse_target,
+            "reference_spp": args.rmse_ref_spp, "reference": "STREAM + MEAN render of the same frame with other seeds",
+            "chunk_spp": chunk, "falloff": "1/r^2 (kernel0.cl:719)", "n_gpus": 1,
+            "curve_spp_ms_rmse": curve[:: max(1, len(curve) // 8)] + curve[-1:],
+        }
+        ctx.use_own_stream()
+        ctx.bind_accum(None)
+        ctx.set_sample_offset(0)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_bind as oracle   # the checker, timed here as the CPU baseline
@@ -336,8 +450,21 @@ def main():
             "value": round(n_paths / cpu_s / 1e6, 6), "unit": "Mpaths/s", "cores": threads, "kind": "port",
             "sample": "%d x %d blocks of %dx%d pixels spread evenly over the %dx%d frame, %d spp, same scene/seeds/mode; %.1f s"
                       % (gx, gy, bw, bh, W, H, cspp, cpu_s),
-            "reference_opencl_on_cpu": cpu_opencl_status(),
         }
+        # the reference's own kernel on a CPU OpenCL device of this host, when there is one: then THAT is the baseline
+        # (kind "reference") and the oracle's figure is kept beside it
+        lines, reason = reference_on_cpu_opencl(scene, scene.camera, bdpt.make_seeds(W, H, 0x5EED), W, H)
+        if lines:
+            port = out["cpu_baseline"]
+            first = lines[0]
+            out["cpu_baseline"] = {
+                "value": round(first["mpaths_per_s"], 6), "unit": "Mpaths/s", "cores": first["compute_units"], "kind": "reference",
+                "sample": "the reference's kernel file built with %s on OpenCL device %r (%d compute units, nproc %d): %d frames of %dx%d, 1 spp each, after 2 warm-up frames; %.1f s"
+                          % (first["build_options"], first["device"], first["compute_units"], first["nproc"], first["frames"], W, H, first["seconds"]),
+                "other_builds": lines[1:], "port": port,
+            }
+        else:
+            out["cpu_baseline"]["reference_opencl_on_cpu"] = reason
 
     if rank == 0:
         print(json.dumps(out), flush=True)

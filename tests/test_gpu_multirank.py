@@ -196,14 +196,15 @@ def test_device_group_in_one_process(bdpt, tmp_path):
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher around it: the bench starts two ranks itself (before it touches the
     GPU), they share the one GPU here and combine over gloo; one JSON line, and the combined image is the mean of the
-    128 samples one context renders alone."""
+    128 samples one context renders alone; the strong-scaling steps that follow render 64 samples in all, 32 per rank."""
     sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
     import bdpt
 
     dump = str(tmp_path / "img.npy")
+    dump_strong = str(tmp_path / "img_strong.npy")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--spp", "64",
-                        "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1", "--dump-image", dump],
+                        "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1", "--dump-image", dump, "--dump-strong-image", dump_strong],
                        capture_output=True, text=True, timeout=500, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -222,3 +223,15 @@ def test_bench_starts_its_own_ranks(tmp_path):
         ctx.render(128)
         want = ctx.read_accum() / 128
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=2e-6)
+    # the strong-scaling steps: the 64 samples of one GPU's step dealt to the two ranks
+    ss = out["strong_scaling"]
+    assert ss["total_spp"] == 64 and ss["spp_per_rank"] == [32, 32] and len(ss["per_rank_kernel_ms"]) == 2
+    assert ss["ms_per_step"] > 0 and abs(ss["mpaths_per_s"] - 320 * 180 * 64 / ss["ms_per_step"] / 1e3) < 0.01 * ss["mpaths_per_s"]
+    with bdpt.Context(320, 180) as ctx:
+        ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM))
+        ctx.upload_scene(scene)
+        ctx.upload_seeds(bdpt.make_seeds(320, 180, 0x5EED))
+        ctx.set_camera(scene.camera)
+        ctx.render(64)
+        want = ctx.read_accum() / 64
+    np.testing.assert_allclose(np.load(dump_strong), want, rtol=1e-6, atol=2e-6)

@@ -288,7 +288,7 @@ int main(int argc, char **argv)
     clGetDeviceInfo(dev, CL_DEVICE_MAX_COMPUTE_UNITS, sizeof units, &units, NULL);
     cl_bool images = CL_FALSE;
     clGetDeviceInfo(dev, CL_DEVICE_IMAGE_SUPPORT, sizeof images, &images, NULL);
-    if (!images) return unavailable("the CPU OpenCL device has no image support (the kernel reads and writes image2d_t)");
+    if (!images) return unavailable("the OpenCL device has no image support (the kernel reads and writes image2d_t)");
     cl_int err = CL_SUCCESS;
     cl_context_properties props[3] = {CL_CONTEXT_PLATFORM, (cl_context_properties)plat, 0};
     cl_context ctx = clCreateContext(props, 1, &dev, NULL, NULL, &err);

@@ -349,8 +349,11 @@ int bdpt_last_launch_ms(bdpt_ctx *ctx, float *ms);
  * 0 -- one RCCL reduce over xGMI (BDPT_COMBINE_RCCL; the library is looked up at run time), or
  * device-to-device copies and an add kernel (BDPT_COMBINE_COPY; also what a group that names one GPU
  * twice uses) -- and returns the mean.  BDPT_COMBINE_AUTO takes RCCL when it loads.  A render call of spp
- * samples gives member r the sample indices [N + r*spp/n, ...) after the N rendered since the last camera
- * change, so the image depends on spp and on the number of GPUs only through the order of float additions.
+ * samples deals the sample indices [N, N + spp) after the N rendered since the last camera change to the
+ * members in contiguous ranges, so the image depends on spp and on the number of GPUs only through the order of
+ * float additions; the left-over samples of a call (spp not a multiple of the group's size, or one sample per
+ * frame) go to the members in turn, so no GPU idles frame after frame.  A render call that fails part-way
+ * leaves the group unusable (BDPT_ERR_STATE) until bdpt_group_set_camera or bdpt_group_upload_scene resets it.
  * Errors: as for contexts, message through bdpt_group_last_error. */
 typedef struct bdpt_group bdpt_group;
 enum { BDPT_COMBINE_AUTO = 0, BDPT_COMBINE_RCCL = 1, BDPT_COMBINE_COPY = 2 };

@@ -572,6 +572,13 @@ class Group:
     def num_samples(self):
         return lib.bdpt_group_num_samples(self._h)
 
+    def member_num_samples(self, i):
+        """Samples member i has rendered since the last reset."""
+        m = lib.bdpt_group_member(self._h, i)
+        if not m:
+            raise IndexError(i)
+        return lib.bdpt_num_samples(m)
+
     def set_params(self, params):
         self._check(lib.bdpt_group_set_params(self._h, C.byref(params)))
 

@@ -58,6 +58,9 @@ struct bdpt_group {
     int width = 0, height = 0;
     int total_samples = 0;                 /* samples per pixel rendered since the last reset, all members together */
     std::vector<int> member_samples;       /* of which by each member */
+    int next_member = 0;                   /* the member that takes the first of the next call's left-over samples: calls of
+                                              fewer samples than members (one sample per frame) go round the members */
+    bool needs_reset = false;              /* a render call failed half-way: the members' counters no longer add up */
     bool use_rccl = false;
     Rccl rccl;
     std::vector<void *> comms;
@@ -174,6 +177,8 @@ static void group_reset(bdpt_group *g)
 {
     g->total_samples = 0;
     for (int &n : g->member_samples) n = 0;
+    g->next_member = 0;
+    g->needs_reset = false;
 }
 
 int bdpt_group_set_params(bdpt_group *g, const bdpt_params *p)
@@ -212,27 +217,47 @@ int bdpt_group_set_camera(bdpt_group *g, const bdpt_camera *cam)
 int bdpt_group_render(bdpt_group *g, int spp)
 {
     if (!g || spp < 1) return gfail(g, BDPT_ERR_INVALID, "bdpt_group_render: bad argument");
+    if (g->needs_reset) return gfail(g, BDPT_ERR_STATE, "bdpt_group_render: an earlier render call failed part-way; reset with bdpt_group_set_camera");
     const int n = (int)g->members.size();
     const int base = spp / n, rem = spp % n;
-    for (int r = 0; r < n; r++) {                                         /* enqueue on every GPU, then wait for all */
-        const int count = base + (r < rem ? 1 : 0);
-        const int first = g->total_samples + r * base + (r < rem ? r : rem);
+    /* Members in the order next_member, next_member + 1, ...: each takes a contiguous range of the call's sample
+     * indices, the first `rem` of them one sample more.  The counters change only when every member has launched
+     * and finished; a failure before that leaves them inconsistent with what the members hold, and the group says
+     * so until it is reset. */
+    std::vector<int> add(n, 0);
+    int first = g->total_samples;
+    for (int k = 0; k < n; k++) {                                         /* enqueue on every GPU, then wait for all */
+        const int r = (g->next_member + k) % n;
+        const int count = base + (k < rem ? 1 : 0);
         if (count == 0) continue;
         bdpt_ctx *m = g->members[r];
         /* the kernel numbers a launch's samples from sample_offset + (the member's own counter) */
         int rc = bdpt_set_sample_offset(m, first - g->member_samples[r]);
         if (rc == BDPT_OK) rc = bdpt_render_async(m, count);
-        if (rc != BDPT_OK) return gfail(g, rc, "member " + std::to_string(r) + ": " + bdpt_last_error(m));
-        g->member_samples[r] += count;
+        if (rc != BDPT_OK) {
+            g->needs_reset = true;
+            return gfail(g, rc, "member " + std::to_string(r) + ": " + bdpt_last_error(m));
+        }
+        add[r] = count;
+        first += count;
     }
-    G_EACH(g, bdpt_sync(m));
+    for (size_t i = 0; i < g->members.size(); i++) {
+        const int rc = bdpt_sync(g->members[i]);
+        if (rc != BDPT_OK) {
+            g->needs_reset = true;
+            return gfail(g, rc, "member " + std::to_string(i) + ": " + bdpt_last_error(g->members[i]));
+        }
+    }
+    for (int r = 0; r < n; r++) g->member_samples[r] += add[r];
     g->total_samples += spp;
+    g->next_member = (g->next_member + rem) % n;
     return BDPT_OK;
 }
 
 int bdpt_group_read_image(bdpt_group *g, float *rgba)
 {
     if (!g || !rgba) return gfail(g, BDPT_ERR_INVALID, "bdpt_group_read_image: null argument");
+    if (g->needs_reset) return gfail(g, BDPT_ERR_STATE, "bdpt_group_read_image: an earlier render call failed part-way; reset with bdpt_group_set_camera");
     if (g->total_samples < 1) return gfail(g, BDPT_ERR_STATE, "bdpt_group_read_image: nothing rendered since the last reset");
     const int n = (int)g->members.size();
     const size_t npix = (size_t)g->width * g->height, bytes = npix * sizeof(float4);

@@ -177,6 +177,17 @@ def test_device_group_in_one_process(bdpt, tmp_path):
     np.testing.assert_allclose(img1, want, rtol=1e-6, atol=1e-6)
     with pytest.raises(bdpt.BdptError, match="distinct"):
         bdpt.Group([0, 0], W, H, bdpt.COMBINE_RCCL)
+    # one sample per frame (the C++ host's default): the frames go round the members, none idles
+    with bdpt.Group([0, 0, 0], W, H, bdpt.COMBINE_AUTO) as g:
+        g.upload_scene(scene)
+        g.upload_seeds(seeds)
+        g.set_camera(scene.camera)
+        for _ in range(7):
+            g.render(1)
+        assert [g.member_num_samples(i) for i in range(3)] == [3, 2, 2]
+        g.render(5)                                    # 1 + 2 left over, starting at member 1
+        assert [g.member_num_samples(i) for i in range(3)] == [4, 4, 4]
+        np.testing.assert_allclose(g.read_image(), _single(bdpt, [12], rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM) / 12, rtol=1e-6, atol=1e-6)
 
     # the C++ host over the same entry points
     exe = os.path.join(ROOT, "opencl-path-tracer_amd", "bdpt_host")

@@ -245,6 +245,21 @@ int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, 
 int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks);
 /* runs per tile the last render call asked its launch for (1 = unsliced) */
 int bdpt_last_launch_chunks(const bdpt_ctx *ctx);
+/* How a render call puts paths on lanes; the result is bit-identical either way.
+ * PER_LANE: a lane owns one pixel for the whole launch and walks each sample of it from the eye ray to the end of its
+ *           light subpath; lanes whose subpath ends early (roulette, kernel0.cl:788; a bounce ray that leaves the scene
+ *           or hits a light, :796-813) wait for the longest subpath of their wavefront.
+ * POOLED:   a wavefront owns more pixels than it has lanes (16 x 6), keeps the state of their paths in LDS, and every
+ *           round runs one phase (eye ray / connection ray / bounce ray, each with what follows it) for up to 64 of
+ *           the paths that wait in that phase, picked by ballot and prefix count: terminated paths cost no lane time.
+ *           A pixel still has one sample in flight at a time, in the launch's order, so generator streams, running
+ *           means and sums are untouched.  For the kernel variants that keep the scene in LDS and the reference's live
+ *           sampler; other launches run PER_LANE whatever is asked (bdpt_last_launch_path_scheduling tells).
+ * AUTO:     PER_LANE.
+ * No reference counterpart. */
+enum { BDPT_PATHS_AUTO = 0, BDPT_PATHS_PER_LANE = 1, BDPT_PATHS_POOLED = 2 };
+int bdpt_set_path_scheduling(bdpt_ctx *ctx, int mode);
+int bdpt_last_launch_path_scheduling(const bdpt_ctx *ctx);
 /* A run of a sliced launch waits for the run before it on the same tile.  That wait always ends unless something
  * else has gone wrong on the device; as a guard, a workgroup that has waited longer than a limit gives up, the rest of
  * the launch drains without touching the image, and the next call that waits for the launch (bdpt_sync, bdpt_render,

@@ -30,6 +30,7 @@ LIGHT_ORIGIN_SELF, LIGHT_ORIGIN_NONE = 0, 1
 FALLOFF_INV_SQ, FALLOFF_INV_SQ_PLUS_C = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_LDS, KERNEL_TILED, KERNEL_LDS2 = 0, 1, 3, 4, 5
+PATHS_AUTO, PATHS_PER_LANE, PATHS_POOLED = 0, 1, 2
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
 SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE, SAMPLER_LAMBERT_IMP = 0, 1, 2, 3
 INTEGRATOR_BIDIRECTIONAL, INTEGRATOR_PATH_TRACE = 0, 1
@@ -106,6 +107,8 @@ lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_launch_chunks.argtypes = [_vp, C.c_int]
 lib.bdpt_last_launch_chunks.argtypes = [_vp]
+lib.bdpt_set_path_scheduling.argtypes = [_vp, C.c_int]
+lib.bdpt_last_launch_path_scheduling.argtypes = [_vp]
 lib.bdpt_two_stage_record_counts.argtypes = [_vp, C.POINTER(C.c_int)]
 lib.bdpt_set_order_scratch_limit.argtypes = [_vp, C.c_size_t]
 lib.bdpt_set_slice_wait_limit.argtypes = [_vp, C.c_double]
@@ -432,6 +435,13 @@ class Context:
     def set_launch_chunks(self, chunks):
         """Runs per tile of a render call (0 = chosen per launch, 1 = unsliced); never changes a result."""
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
+
+    def set_path_scheduling(self, mode):
+        """PATHS_PER_LANE or PATHS_POOLED (a wavefront's paths sorted by phase); never changes a result."""
+        self._check(lib.bdpt_set_path_scheduling(self._h, mode))
+
+    def last_launch_path_scheduling(self):
+        return lib.bdpt_last_launch_path_scheduling(self._h)
 
     def set_order_scratch_limit(self, nbytes):
         """Device memory the context may take for the table that keeps a launch's class order (0: none); never changes a result."""

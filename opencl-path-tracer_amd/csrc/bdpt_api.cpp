@@ -81,6 +81,8 @@ struct bdpt_ctx {
     uint32_t *h_slice_abort = nullptr, *d_slice_abort = nullptr;
     double slice_wait_s = 0.0;         /* bdpt_set_slice_wait_limit: 0 = derived from the expected launch time */
     double steady_ticks_per_ms = 1.0e5; /* the device's steady counter (wall_clock64): 100 MHz unless the device says otherwise */
+    int path_scheduling = BDPT_PATHS_AUTO;   /* bdpt_set_path_scheduling */
+    int last_path_scheduling = 0;      /* BDPT_PATHS_PER_LANE or BDPT_PATHS_POOLED: how the last launch ran */
     int last_order_table = 0;          /* the last launch took its class order from the table (1) or worked it out as it went (0) */
     double ms_per_pixel_sample = 0.0;  /* measured on an earlier launch of this scene and these parameters; 0 = not yet */
     double last_launch_work = 0.0;     /* pixels x samples of the last launch, until its time has been read */
@@ -207,6 +209,12 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if (const char *env = std::getenv("BDPT_LAUNCH_CHUNKS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 0 && v <= 4096) ctx->launch_chunks = (int)v;
+    }
+    /* BDPT_PATH_SCHEDULING in the environment: the initial bdpt_set_path_scheduling of every context (to run an existing
+     * program or test suite with the pooled launch form wherever it applies) */
+    if (const char *env = std::getenv("BDPT_PATH_SCHEDULING")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= BDPT_PATHS_AUTO && v <= BDPT_PATHS_POOLED) ctx->path_scheduling = (int)v;
     }
     const size_t npix = (size_t)width * height;
     auto bail = [&](hipError_t err, const char *what) {
@@ -947,12 +955,17 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         }
         K.slice_wait_ticks = (unsigned long long)std::min(1.0e18, wait_ms * ctx->steady_ticks_per_ms);
     }
+    /* paths sorted by phase inside a wavefront (bdpt_pool.h), where the launch allows it */
+    const bool pooled = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && ctx->path_scheduling == BDPT_PATHS_POOLED &&
+                        bdpt_pool_supported(K, variant);
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    ctx->last_path_scheduling = pooled ? BDPT_PATHS_POOLED : BDPT_PATHS_PER_LANE;
     if (ctx->params.integrator == BDPT_INTEGRATOR_PATH_TRACE) {
         variant = BDPT_KERNEL_DIRECT;
         HIP_TRY(ctx, bdpt_launch_path_trace(K, aov, ctx->stream));
-    } else if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
+    } else if (pooled) HIP_TRY(ctx, bdpt_launch_pool(K, variant, aov, ctx->counters_on, ctx->stream));
+    else if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS2) HIP_TRY(ctx, bdpt_launch_lds2(K, aov, ctx->counters_on, ctx->stream));
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
@@ -997,6 +1010,17 @@ int bdpt_set_slice_wait_limit(bdpt_ctx *ctx, double seconds)
 }
 
 int bdpt_last_launch_order_table(const bdpt_ctx *ctx) { return ctx ? ctx->last_order_table : 0; }
+
+int bdpt_set_path_scheduling(bdpt_ctx *ctx, int mode)
+{
+    if (!ctx) return BDPT_ERR_INVALID;
+    if (mode < BDPT_PATHS_AUTO || mode > BDPT_PATHS_POOLED) return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_path_scheduling: unknown mode");
+    ctx->path_scheduling = mode;
+    ctx->ms_per_pixel_sample = ctx->last_launch_work = 0.0;               /* another launch form, another cost per sample */
+    return BDPT_OK;
+}
+
+int bdpt_last_launch_path_scheduling(const bdpt_ctx *ctx) { return ctx ? ctx->last_path_scheduling : 0; }
 
 int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes)
 {

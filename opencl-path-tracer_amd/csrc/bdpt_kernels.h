@@ -22,6 +22,12 @@ hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream
 /* The same work for scenes of any size: triangle records staged through wave-private LDS tiles. */
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
+/* The same work with a wavefront's paths sorted by phase (bdpt_pool.h): a wavefront owns more pixels than lanes and runs,
+ * every round, the phase most of their paths wait in.  variant: BDPT_KERNEL_LDS or BDPT_KERNEL_LDS2 (how the search reads
+ * the scene).  Not every launch can run this way; ask first. */
+bool bdpt_pool_supported(const bdpt_kargs &K, int variant);
+hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream);
+
 /* The reference's older unidirectional kernel (kernel0.cl:872-1001): spp samples per pixel of the region in one launch. */
 hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream);
 

@@ -19,6 +19,8 @@
 #include "bdpt_slice.h"
 #include "bdpt_kernels.h"
 
+#include <algorithm>
+
 /* Workgroup: one wavefront (one 8x8 pixel tile) or two (two tiles side by side), chosen per launch (launch_block).
  * One is faster where it fits (1080p Cornell box, 1024 spp: 129.9 against 133.0 ms; 100 000 triangles 915 against
  * 944 ms per 4 samples): a workgroup's slot is free as soon as its wavefront ends, and the barriers of a sliced launch
@@ -1280,11 +1282,17 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 
 }  // namespace bdpt
 
+#include "bdpt_pool.h"
+
 /* ---- launch wrappers ------------------------------------------------------ */
 
 /* grid of a per-pixel launch: see lane_pixel */
 static dim3 pixel_grid(const bdpt_kargs &K)
 {
+    if (K.pool_rows) {                                   /* whole region only: see bdpt_pool_supported */
+        const int block_w = (K.block >> 6) * BDPT_POOL_W;
+        return dim3((K.rw + block_w - 1) / block_w, (K.rh + K.pool_rows - 1) / K.pool_rows);
+    }
     const int block_w = K.block >> 3;
     if (K.tile_stride <= 1) return dim3((K.rw + block_w - 1) / block_w, (K.rh + 7) / 8);
     const int tiles_y = (K.rh + K.tile_h - 1) / K.tile_h, n_tiles = K.tiles_x * tiles_y;
@@ -1371,6 +1379,53 @@ hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_
 hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     return launch_per_pixel<bdpt::MODE_LDS2>(K, aov, count, stream);
+}
+
+/* Paths sorted by phase (bdpt_pool.h).  Wavefronts per workgroup: as many as keep the most wavefronts on a compute unit
+ * (one copy of the scene per workgroup, one pool per wavefront, 160 KB of LDS per compute unit, 64 KB per workgroup). */
+bool bdpt_pool_supported(const bdpt_kargs &K, int variant)
+{
+    if (variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2) return false;
+    if (K.sampler != BDPT_SAMPLER_LAMBERT_CONE || K.tile_stride > 1) return false;
+    if (variant == BDPT_KERNEL_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return false;
+    return bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
+}
+
+template <int MODE>
+static hipError_t launch_pool(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    const size_t scene = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2), pool = (size_t)BDPT_POOL_WAVE_F4 * sizeof(float4);
+    int nw = 1;
+    size_t best = 0;
+    for (int n = 1; n <= 4; n++) {
+        const size_t wg = scene + n * pool + 64;                              /* + the words slice_begin keeps */
+        if (wg > 64 * 1024) break;
+        const size_t waves = std::min((size_t)(160 * 1024) / wg, (size_t)32 / n) * n;
+        if (waves > best) { best = waves; nw = n; }
+    }
+    if (best == 0) return hipErrorInvalidValue;
+    K.block = 64 * nw;
+    K.pool_rows = BDPT_POOL_ROWS;
+    const size_t lds = scene + nw * pool;
+    dim3 grid;
+    const dim3 block(K.block);
+    const hipError_t e = sliced_grid(K, grid, stream);
+    if (e != hipSuccess) return e;
+    if (grid.x == 0) return hipSuccess;
+#define BDPT_LAUNCH(A, C) hipLaunchKernelGGL((bdpt::bdpt_pool_kernel<A, C, MODE>), grid, block, lds, stream, K)
+    if (aov && count) BDPT_LAUNCH(true, true);
+    else if (aov) BDPT_LAUNCH(true, false);
+    else if (count) BDPT_LAUNCH(false, true);
+    else BDPT_LAUNCH(false, false);
+#undef BDPT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream)
+{
+    if (!bdpt_pool_supported(K, variant)) return hipErrorInvalidValue;
+    return variant == BDPT_KERNEL_LDS2 ? launch_pool<bdpt::MODE_LDS2>(K, aov, count, stream) : launch_pool<bdpt::MODE_LDS>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K_in, bool aov, bool count, hipStream_t stream)

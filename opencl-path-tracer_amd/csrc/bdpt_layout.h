@@ -118,6 +118,7 @@ struct bdpt_kargs {
     int mask_words;
     int n_chunks, chunk_spp, n_tiles, wg_x;
     int block;                  /* threads per workgroup, 64 or 128: one 8x8-pixel tile per wavefront, side by side (set by the launcher) */
+    int pool_rows;              /* 0: one lane per pixel.  Else the launch sorts its paths by phase (bdpt_pool.h): a wavefront owns 16 x pool_rows pixels, block / 64 wavefronts side by side */
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;
     uint32_t first_sample;      /* STRIDED: sample_offset + num_samples */

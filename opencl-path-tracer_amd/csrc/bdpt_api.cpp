@@ -70,6 +70,9 @@ struct bdpt_ctx {
     unsigned long long *d_counters = nullptr;
     uint32_t *d_slice_sync = nullptr;  /* sliced launches: ticket counter + one word per workgroup tile */
     uint4 *d_slice_cursor = nullptr;   /* ... and a sample cursor per pixel */
+    float *d_xt_tab = nullptr, *d_yt_tab = nullptr;   /* screen coordinate of every pixel column / row (kernel0.cl:600-604) */
+    float4 *d_pool_state = nullptr;    /* pooled launches: path state that waits in device memory (bdpt_kargs.pool_state), allocated by the first launch that wants it */
+    size_t pool_state_bytes = 0;
     uint32_t *d_class_masks = nullptr; /* class order from a table (bdpt_kargs.class_masks), allocated by the first launch that wants it */
     size_t class_mask_bytes = 0;       /* its size */
     size_t order_scratch_limit = BDPT_ORDER_SCRATCH_DEFAULT;   /* bdpt_set_order_scratch_limit */
@@ -96,6 +99,13 @@ struct bdpt_ctx {
 #endif
 #ifndef BDPT_AUTO_CHUNK_MIN_SPP
 #define BDPT_AUTO_CHUNK_MIN_SPP 32
+#endif
+/* pooled launches (bdpt_pool.h): up to this many runs, of at least this many samples */
+#ifndef BDPT_POOL_AUTO_CHUNKS
+#define BDPT_POOL_AUTO_CHUNKS 8
+#endif
+#ifndef BDPT_POOL_AUTO_CHUNK_MIN_SPP
+#define BDPT_POOL_AUTO_CHUNK_MIN_SPP 128
 #endif
 /* what one more run costs per pixel (its state re-read and re-written): 1.06 ms per run of a 3840x2160 frame */
 #define BDPT_RUN_COST_MS_PER_PIXEL 1.28e-7
@@ -239,6 +249,15 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if ((e = hipMalloc((void **)&ctx->d_slice_sync, slice_bytes)) != hipSuccess) return bail(e, "hipMalloc slice words");
     if ((e = hipMemset(ctx->d_slice_sync, 0, slice_bytes)) != hipSuccess) return bail(e, "hipMemset slice words");
     if ((e = hipMalloc((void **)&ctx->d_slice_cursor, npix * sizeof(uint4))) != hipSuccess) return bail(e, "hipMalloc slice cursors");
+    {
+        /* kernel0.cl:600-604 for every column and row, with the arithmetic of pixel_coord (bdpt_device.h) */
+        std::vector<float> xt((size_t)width), yt((size_t)height);
+        const float aspect = clm_div((float)width * 1.0f, (float)height);
+        for (int x = 0; x < width; x++) xt[x] = (float)(((double)clm_div((float)x, (float)width) * 2.0 - 1.0) * (double)aspect);
+        for (int y = 0; y < height; y++) yt[y] = (float)((double)clm_div((float)y, (float)height) * 2.0 - 1.0);
+        if ((e = dev_upload(ctx->d_xt_tab, xt)) != hipSuccess) return bail(e, "pixel column table");
+        if ((e = dev_upload(ctx->d_yt_tab, yt)) != hipSuccess) return bail(e, "pixel row table");
+    }
     if ((e = hipHostMalloc((void **)&ctx->h_slice_abort, sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc give-up mark");
     *ctx->h_slice_abort = 0u;
     if ((e = hipHostGetDevicePointer((void **)&ctx->d_slice_abort, ctx->h_slice_abort, 0)) != hipSuccess) return bail(e, "hipHostGetDevicePointer");
@@ -261,7 +280,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
     dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters); dev_free(ctx->d_slice_sync); dev_free(ctx->d_slice_cursor);
-    dev_free(ctx->d_class_masks);
+    dev_free(ctx->d_class_masks); dev_free(ctx->d_pool_state); dev_free(ctx->d_xt_tab); dev_free(ctx->d_yt_tab);
     if (ctx->h_slice_abort) (void)hipHostFree(ctx->h_slice_abort);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -797,6 +816,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.slice_sync = ctx->d_slice_sync;
     K.slice_cursor = ctx->d_slice_cursor;
     K.slice_abort = ctx->d_slice_abort;
+    K.xt_tab = ctx->d_xt_tab; K.yt_tab = ctx->d_yt_tab;
     K.n_tiles = ctx->slice_tiles;                                       /* room; the launcher puts the launch's count here */
     K.n_chunks = 1;
     K.chunk_spp = spp;
@@ -955,9 +975,40 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         }
         K.slice_wait_ticks = (unsigned long long)std::min(1.0e18, wait_ms * ctx->steady_ticks_per_ms);
     }
-    /* paths sorted by phase inside a wavefront (bdpt_pool.h), where the launch allows it */
-    const bool pooled = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && ctx->path_scheduling == BDPT_PATHS_POOLED &&
-                        bdpt_pool_supported(K, variant);
+    /* Paths sorted by phase inside a wavefront (bdpt_pool.h), where the launch allows it.  Part of a path's state waits
+     * in device memory, every run of a tile in a region of its own: kept from launch to launch, grown when a launch needs
+     * more (never while the stream is being captured), and a launch that cannot have it runs one lane per pixel. */
+    bool pooled = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && ctx->path_scheduling == BDPT_PATHS_POOLED &&
+                  bdpt_pool_supported(K, variant);
+    if (pooled) {
+        if (ctx->launch_chunks == 0) {                   /* long runs keep a pool full; few runs keep the state small */
+            const int chunks = std::max(1, std::min(BDPT_POOL_AUTO_CHUNKS, spp / BDPT_POOL_AUTO_CHUNK_MIN_SPP));
+            K.chunk_spp = (spp + chunks - 1) / chunks;
+            K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
+        }
+        size_t bytes = bdpt_pool_state_bytes(K, variant, K.n_chunks);
+        while (K.n_chunks > 1 && bytes > ctx->order_scratch_limit) {
+            const int chunks = K.n_chunks / 2;
+            K.chunk_spp = (spp + chunks - 1) / chunks;
+            K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
+            bytes = bdpt_pool_state_bytes(K, variant, K.n_chunks);
+        }
+        if (bytes > ctx->pool_state_bytes && bytes <= ctx->order_scratch_limit) {
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &capturing) != hipSuccess) (void)hipGetLastError();
+            if (capturing == hipStreamCaptureStatusNone) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));              /* an earlier launch may still use the old one */
+                dev_free(ctx->d_pool_state);
+                ctx->pool_state_bytes = 0;
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = 0; (void)hipGetLastError(); }
+                if (bytes <= free_b / 2 && hipMalloc((void **)&ctx->d_pool_state, bytes) == hipSuccess) ctx->pool_state_bytes = bytes;
+                else { ctx->d_pool_state = nullptr; (void)hipGetLastError(); }
+            }
+        }
+        if (bytes == 0 || bytes > ctx->pool_state_bytes) pooled = false;
+        else K.pool_state = ctx->d_pool_state;
+    }
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     ctx->last_path_scheduling = pooled ? BDPT_PATHS_POOLED : BDPT_PATHS_PER_LANE;

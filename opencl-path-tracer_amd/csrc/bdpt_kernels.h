@@ -26,6 +26,8 @@ hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStrea
  * every round, the phase most of their paths wait in.  variant: BDPT_KERNEL_LDS or BDPT_KERNEL_LDS2 (how the search reads
  * the scene).  Not every launch can run this way; ask first. */
 bool bdpt_pool_supported(const bdpt_kargs &K, int variant);
+/* bytes of K.pool_state such a launch of K's region needs when it is cut into `chunks` runs per tile */
+size_t bdpt_pool_state_bytes(const bdpt_kargs &K, int variant, int chunks);
 hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream);
 
 /* The reference's older unidirectional kernel (kernel0.cl:872-1001): spp samples per pixel of the region in one launch. */

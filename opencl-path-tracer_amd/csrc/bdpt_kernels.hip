@@ -1391,12 +1391,11 @@ bool bdpt_pool_supported(const bdpt_kargs &K, int variant)
     return bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
 }
 
-template <int MODE>
-static hipError_t launch_pool(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
+/* wavefronts per workgroup of a pooled launch, and the bytes of K.pool_state it needs for `chunks` runs per tile */
+static int pool_waves_per_workgroup(const bdpt_kargs &K, int variant)
 {
-    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
-    const size_t scene = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2), pool = (size_t)BDPT_POOL_WAVE_F4 * sizeof(float4);
-    int nw = 1;
+    const size_t scene = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2), pool = (size_t)BDPT_POOL_WAVE_F4 * sizeof(float4);
+    int nw = 0;
     size_t best = 0;
     for (int n = 1; n <= 4; n++) {
         const size_t wg = scene + n * pool + 64;                              /* + the words slice_begin keeps */
@@ -1404,10 +1403,28 @@ static hipError_t launch_pool(bdpt_kargs K, bool aov, bool count, hipStream_t st
         const size_t waves = std::min((size_t)(160 * 1024) / wg, (size_t)32 / n) * n;
         if (waves > best) { best = waves; nw = n; }
     }
-    if (best == 0) return hipErrorInvalidValue;
+    return nw;
+}
+
+size_t bdpt_pool_state_bytes(const bdpt_kargs &K, int variant, int chunks)
+{
+    const int nw = pool_waves_per_workgroup(K, variant);
+    if (nw == 0) return 0;
+    const size_t block_w = (size_t)nw * BDPT_POOL_W;
+    const size_t tiles = ((K.rw + block_w - 1) / block_w) * ((K.rh + BDPT_POOL_ROWS - 1) / BDPT_POOL_ROWS);
+    return tiles * (size_t)std::max(1, chunks) * nw * BDPT_POOL_SLOTS * BDPT_POOL_GLOBAL_F4 * sizeof(float4);
+}
+
+template <int MODE>
+static hipError_t launch_pool(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0 || !K.pool_state || !K.xt_tab || !K.yt_tab) return hipErrorInvalidValue;
+    const int variant = MODE == bdpt::MODE_LDS2 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;
+    const int nw = pool_waves_per_workgroup(K, variant);
+    if (nw == 0) return hipErrorInvalidValue;
     K.block = 64 * nw;
     K.pool_rows = BDPT_POOL_ROWS;
-    const size_t lds = scene + nw * pool;
+    const size_t lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2) + (size_t)nw * BDPT_POOL_WAVE_F4 * sizeof(float4);
     dim3 grid;
     const dim3 block(K.block);
     const hipError_t e = sliced_grid(K, grid, stream);

@@ -84,6 +84,14 @@ struct bdpt_dev_scene {
 
 #define BDPT_INV_PRE_N 8
 
+/* launches that sort a wavefront's paths by phase (bdpt_pool.h): a wavefront owns BDPT_POOL_W x BDPT_POOL_ROWS pixels and keeps
+ * BDPT_POOL_GLOBAL_F4 float4 of path state per pixel in device memory */
+#define BDPT_POOL_W 16
+#ifndef BDPT_POOL_ROWS
+#define BDPT_POOL_ROWS 6
+#endif
+#define BDPT_POOL_GLOBAL_F4 4
+
 struct bdpt_kargs {
     bdpt_dev_scene scene;
     /* per-pixel state, row-major y*width + x */
@@ -118,6 +126,8 @@ struct bdpt_kargs {
     int mask_words;
     int n_chunks, chunk_spp, n_tiles, wg_x;
     int block;                  /* threads per workgroup, 64 or 128: one 8x8-pixel tile per wavefront, side by side (set by the launcher) */
+    float4 *pool_state;         /* pooled launches: BDPT_POOL_GLOBAL_F4 float4 per pixel slot, one region per run of a tile and wavefront */
+    const float *xt_tab, *yt_tab;   /* the normalised screen coordinate of every pixel column and row (kernel0.cl:600-604) */
     int pool_rows;              /* 0: one lane per pixel.  Else the launch sorts its paths by phase (bdpt_pool.h): a wavefront owns 16 x pool_rows pixels, block / 64 wavefronts side by side */
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;

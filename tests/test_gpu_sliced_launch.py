@@ -147,6 +147,7 @@ def test_benchmark_sized_launch_sliced_automatically(bdpt):
         ctx.upload_seeds(bdpt.make_seeds(size[0], size[1], 0x5EED))
         ctx.set_camera(scene.camera)
         ctx.set_launch_chunks(0)                       # automatic, whatever BDPT_LAUNCH_CHUNKS says
+        ctx.set_path_scheduling(bdpt.PATHS_PER_LANE)   # ... and one lane per pixel, whatever BDPT_PATH_SCHEDULING says
         ctx.render(1024)
         assert ctx.last_launch_chunks() == 16 and ctx.last_launch_variant() == bdpt.KERNEL_LDS2
         sliced = ctx.read_accum()

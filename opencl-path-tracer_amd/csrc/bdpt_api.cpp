@@ -519,7 +519,20 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_sph, sph));
     HIP_TRY(ctx, dev_upload(ctx->d_pln, pln));
     HIP_TRY(ctx, dev_upload(ctx->d_tri, tri));
-    HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, bound));
+    {
+        /* the bounding spheres as the tiled kernel reads them: two spheres A, B per pair of float4, component by component,
+         * (cx_A, cx_B, cy_A, cy_B), (cz_A, cz_B, w_A, w_B), so that one packed instruction works on both (bdpt_layout.h);
+         * an odd count is completed by a sphere that is out of every ray's reach */
+        const size_t pairs = ((size_t)n_triangles + 2) / 2;
+        std::vector<float4> paired(pairs * 2);
+        for (size_t j = 0; j < pairs; j++) {
+            const float4 A = 2 * j < (size_t)n_triangles ? bound[2 * j] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            const float4 B = 2 * j + 1 < (size_t)n_triangles ? bound[2 * j + 1] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            paired[2 * j] = make_float4(A.x, B.x, A.y, B.y);
+            paired[2 * j + 1] = make_float4(A.z, B.z, A.w, B.w);
+        }
+        HIP_TRY(ctx, dev_upload(ctx->d_tri_bound, paired));
+    }
     /* The conservative test's records in the order the test walks them (bdpt_layout.h), per group of 32 triangles:
      * the pairs that share a plane (equal normal and a.n, wherever in the group they are) -- first those
      * that are the two halves of a parallelogram, whose second triangle needs no planes of its own -- then the rest. */

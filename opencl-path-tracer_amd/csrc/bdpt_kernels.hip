@@ -830,6 +830,7 @@ BDPT_DEV void direct_pixel(const bdpt_kargs &K, const Slice &sl, int x, int y)
 
 #define BDPT_TILE_TRIS 192                               /* bounding spheres per tile: 3 float4 per lane */
 #define BDPT_TILE_F4 BDPT_TILE_TRIS
+typedef float pk_f2 __attribute__((ext_vector_type(2)));   /* two floats in a register pair, for the packed two-wide instructions */
 
 /* COUNT: also count, per lane, the bounding-sphere tests made and the triangle tests that followed them */
 template <bool COUNT = false>
@@ -862,7 +863,7 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
     const float bound = fabsf(dd - 1.0f) <= 4.0e-6f ? 1.0e-5f * (oo + 1.0f) + 2.0e-6f * oo - 0.99999f * oo : INFINITY;
     const clm_f3 o2 = clm_scale3(-2.0f * 0.99999f, o);                      /* the factor of c.o, folded into the ray's side (one more rounding of 6e-8 |c||o|) */
     const int n_tiles = (S.n_triangles + BDPT_TILE_TRIS - 1) / BDPT_TILE_TRIS;
-    const size_t total_f4 = (size_t)S.n_triangles + 1;                     /* the array is padded by one sphere */
+    const size_t total_f4 = ((size_t)S.n_triangles + 2) / 2 * 2;           /* whole pairs of spheres */
     float4 r0, r1, r2;                                                     /* this lane's three float4 of the next tile */
     auto fetch = [&](int tile) {
         const size_t base = (size_t)tile * BDPT_TILE_F4 + lane;
@@ -870,6 +871,9 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
         r1 = S.tri_bound[base + 64 < total_f4 ? base + 64 : 0];
         r2 = S.tri_bound[base + 128 < total_f4 ? base + 128 : 0];
     };
+    /* the ray's constants, each in both halves of a register pair */
+    const pk_f2 dx2 = {d.x, d.x}, dy2 = {d.y, d.y}, dz2 = {d.z, d.z}, nod2 = {-od, -od};
+    const pk_f2 ox2 = {o2.x, o2.x}, oy2 = {o2.y, o2.y}, oz2 = {o2.z, o2.z};
     if (n_tiles > 0) fetch(0);
     for (int tile = 0; tile < n_tiles; tile++) {
         float4 *buf = wave_lds + (tile & 1) * BDPT_TILE_F4;
@@ -882,12 +886,16 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
             const int first = tile * BDPT_TILE_TRIS;
             const int count = min(BDPT_TILE_TRIS, S.n_triangles - first);
             if (COUNT) *n_cull += (unsigned long long)count;
-            auto excess = [&](float4 s) {                                    /* see the margin above: seven fused operations */
-                const float u = __builtin_fmaf(s.z, d.z, __builtin_fmaf(s.y, d.y, __builtin_fmaf(s.x, d.x, -od)));
-                const float t = __builtin_fmaf(s.z, o2.z, __builtin_fmaf(s.y, o2.y, __builtin_fmaf(s.x, o2.x, s.w)));
-                return __builtin_fmaf(-u, u, t);
+            /* see the margin above: seven fused operations per sphere, here as seven packed ones (v_pk_fma_f32) for the two
+             * spheres of a pair -- the same operations on the same numbers as one sphere at a time */
+            auto excess2 = [&](float4 a, float4 bb) {
+                const pk_f2 cx = {a.x, a.y}, cy = {a.z, a.w}, cz = {bb.x, bb.y}, w = {bb.z, bb.w};
+                const pk_f2 u = __builtin_elementwise_fma(cz, dz2, __builtin_elementwise_fma(cy, dy2, __builtin_elementwise_fma(cx, dx2, nod2)));
+                const pk_f2 t = __builtin_elementwise_fma(cz, oz2, __builtin_elementwise_fma(cy, oy2, __builtin_elementwise_fma(cx, ox2, w)));
+                return __builtin_elementwise_fma(-u, u, t);
             };
             auto full = [&](int i, bool wanted) {                            /* the reference's test, for the lanes that want it */
+                wanted = wanted && i < S.n_triangles;                        /* the sphere that completes an odd count has no triangle */
                 if (__builtin_amdgcn_ballot_w64(wanted) == 0) return;
                 const size_t r = (size_t)i * BDPT_TRI_F4;
                 const float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2),
@@ -896,35 +904,32 @@ BDPT_DEV Hit closest_hit_tiled(const bdpt_dev_scene &S, float4 *wave_lds, bool a
                 if (wanted) test_triangle_scattered(b, q0, q1, q2, q3, q4, e2z, i, skip_t, o, d);
                 if (COUNT && wanted) ++*n_exact;
             };
+            const int n_pairs = (count + 1) / 2;
             int j = 0;
-            for (; j + 8 <= count; j += 8) {                                 /* eight spheres per LDS round trip and per compare: 8 % faster than four (100 000 triangles) */
-                const float4 s0 = buf[j], s1 = buf[j + 1], s2 = buf[j + 2], s3 = buf[j + 3], s4 = buf[j + 4], s5 = buf[j + 5], s6 = buf[j + 6], s7 = buf[j + 7];
-                const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3), e4 = excess(s4), e5 = excess(s5), e6 = excess(s6), e7 = excess(s7);
-                const float least = __builtin_fminf(__builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3)), __builtin_fminf(__builtin_fminf(e4, e5), __builtin_fminf(e6, e7)));
+            for (; j + 4 <= n_pairs; j += 4) {                               /* eight spheres per LDS round trip and per compare */
+                const float4 a0 = buf[2 * j], b0 = buf[2 * j + 1], a1 = buf[2 * j + 2], b1 = buf[2 * j + 3], a2 = buf[2 * j + 4], b2 = buf[2 * j + 5],
+                             a3 = buf[2 * j + 6], b3 = buf[2 * j + 7];
+                const pk_f2 e0 = excess2(a0, b0), e1 = excess2(a1, b1), e2 = excess2(a2, b2), e3 = excess2(a3, b3);
+                /* one compare for the eight: no input here is a NaN (upload replaces what could make one by an infinity) */
+                const float least = __builtin_fminf(__builtin_fminf(__builtin_fminf(e0.x, e0.y), __builtin_fminf(e1.x, e1.y)),
+                                                    __builtin_fminf(__builtin_fminf(e2.x, e2.y), __builtin_fminf(e3.x, e3.y)));
                 if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
-                    full(first + j, !(e0 > bound));
-                    full(first + j + 1, !(e1 > bound));
-                    full(first + j + 2, !(e2 > bound));
-                    full(first + j + 3, !(e3 > bound));
-                    full(first + j + 4, !(e4 > bound));
-                    full(first + j + 5, !(e5 > bound));
-                    full(first + j + 6, !(e6 > bound));
-                    full(first + j + 7, !(e7 > bound));
+                    const int i0 = first + 2 * j;
+                    full(i0, !(e0.x > bound));
+                    full(i0 + 1, !(e0.y > bound));
+                    full(i0 + 2, !(e1.x > bound));
+                    full(i0 + 3, !(e1.y > bound));
+                    full(i0 + 4, !(e2.x > bound));
+                    full(i0 + 5, !(e2.y > bound));
+                    full(i0 + 6, !(e3.x > bound));
+                    full(i0 + 7, !(e3.y > bound));
                 }
             }
-            for (; j + 4 <= count; j += 4) {
-                const float4 s0 = buf[j], s1 = buf[j + 1], s2 = buf[j + 2], s3 = buf[j + 3];
-                const float e0 = excess(s0), e1 = excess(s1), e2 = excess(s2), e3 = excess(s3);
-                /* one compare for the four: no input here is a NaN (upload replaces what could make one by -inf) */
-                const float least = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
-                if (__builtin_amdgcn_ballot_w64(!(least > bound)) != 0) {
-                    full(first + j, !(e0 > bound));
-                    full(first + j + 1, !(e1 > bound));
-                    full(first + j + 2, !(e2 > bound));
-                    full(first + j + 3, !(e3 > bound));
-                }
+            for (; j < n_pairs; j++) {
+                const pk_f2 e = excess2(buf[2 * j], buf[2 * j + 1]);
+                full(first + 2 * j, !(e.x > bound));
+                full(first + 2 * j + 1, !(e.y > bound));
             }
-            for (; j < count; j++) full(first + j, !(excess(buf[j]) > bound));
         }
         __builtin_amdgcn_wave_barrier();
     }

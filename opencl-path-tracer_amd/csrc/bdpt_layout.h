@@ -20,7 +20,10 @@
  *                                     shading normal of kernel0.cl:467
  *   triangle bound 1 x float4 : (centre c, (1 - 1e-5 - 2e-6) |c|^2 - 1.05 radius^2) of a sphere around the three
  *       vertices: what the tiled kernel streams; a ray that passes the sphere by more than
- *       rounding can explain cannot hit the triangle, and only the others read the record
+ *       rounding can explain cannot hit the triangle, and only the others read the record.  Stored two spheres
+ *       A, B (triangles 2j, 2j+1) per pair of float4, component by component: (cx_A, cx_B, cy_A, cy_B),
+ *       (cz_A, cz_B, w_A, w_B) -- the operands of packed two-wide instructions; an odd count ends with a
+ *       sphere of w = +inf, which no ray reaches
  *   triangle cull : what the two-stage LDS kernel's conservative test reads, computed in double at upload and
  *       rounded (the test carries a margin for that, see closest_hit_lds2).  Per triangle:
  *       c0 (n.x, n.y, n.z, k)       n as in q0 (the reference's normal, same bits), k = a.n
@@ -70,7 +73,7 @@ struct bdpt_dev_scene {
     const float4 *pln;          /* [n_planes * BDPT_PLN_F4] */
     const uint32_t *pln_surf;   /* [n_planes] */
     const float4 *tri;          /* [(n_triangles + 1) * BDPT_TRI_F4] */
-    const float4 *tri_bound;    /* [n_triangles + 1] bounding spheres */
+    const float4 *tri_bound;    /* [2 * ceil((n_triangles + 1) / 2)] bounding spheres, in pairs */
     const float4 *tri_cull;     /* [cull_f4] records of the conservative test; empty for scenes of more than BDPT_CULL_MAX_TRIANGLES */
     int cull_f4;
     float cull_c;               /* scene constant of that test's margin */

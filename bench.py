@@ -372,6 +372,20 @@ def main():
             out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
                                   "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
                                   "what": "rng_mode STREAM + accum_mode MEAN: the reference's own generator and running mean, one launch"}
+            # the same launch with a wavefront's paths sorted by phase (bdpt_set_path_scheduling POOLED): built to take
+            # the roulette divergence out of this mode; reported beside the per-lane launch, whichever is faster
+            if ctx.last_launch_variant() in (bdpt.KERNEL_LDS, bdpt.KERNEL_LDS2):
+                ctx.set_path_scheduling(bdpt.PATHS_POOLED)
+                ctx.set_camera(scene.camera)
+                ctx.render(SPP)
+                ctx.num_samples = 0
+                ctx.render(SPP)
+                if ctx.last_launch_path_scheduling() == bdpt.PATHS_POOLED:
+                    out["stream_mode"]["pooled"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
+                                                    "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
+                                                    "runs_per_tile": ctx.last_launch_chunks(),
+                                                    "what": "96 pixels per wavefront, one phase per round for up to 64 of their paths"}
+                ctx.set_path_scheduling(bdpt.PATHS_AUTO)
             ctx.set_params(bench_params)
 
     # The second half of the headline metric: wall time from a camera reset until the accumulated image is within

@@ -2,7 +2,7 @@
 bench workload (Cornell, 1920x1080 unless overridden) through the C-ABI, no torch.
 
     python3 tools/prof_run.py [--spp 128] [--launches 2] [--scene cornell|soup:N|outdoor|planes]
-                              [--width W --height H] [--mode strided|stream] [--kernel K] [--chunks C]
+                              [--width W --height H] [--mode strided|stream] [--kernel K] [--chunks C] [--paths 1|2]
 """
 import argparse
 import os
@@ -21,6 +21,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mode", default="strided")
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--chunks", type=int, default=0, help="bdpt_set_launch_chunks (0 = automatic, 1 = unsliced)")
+ap.add_argument("--paths", type=int, default=0, help="bdpt_set_path_scheduling (1 = one lane per pixel, 2 = pooled)")
 ap.add_argument("--order-scratch", type=int, default=-1, help="bdpt_set_order_scratch_limit in MiB (-1 = the default)")
 a = ap.parse_args()
 
@@ -37,6 +38,7 @@ ctx.upload_scene(scene)
 ctx.upload_seeds(bdpt.make_seeds(a.width, a.height, 0x5EED))
 ctx.set_camera(scene.camera)
 ctx.set_launch_chunks(a.chunks)
+ctx.set_path_scheduling(a.paths)
 if a.order_scratch >= 0:
     ctx.set_order_scratch_limit(a.order_scratch << 20)
 ctx.render(min(a.spp, 8))
@@ -46,6 +48,6 @@ for _ in range(a.launches):
     ctx.render(a.spp)
     ms.append(ctx.last_launch_ms())
 paths = a.width * a.height * a.spp
-print("scene=%s %dx%d spp=%d kernel=%d: %s ms -> %.1f Mpaths/s" % (a.scene, a.width, a.height, a.spp, a.kernel,
-      ["%.3f" % m for m in ms], paths / (min(ms) / 1e3) / 1e6))
+print("scene=%s %dx%d spp=%d kernel=%d mode=%s paths=%d: %s ms -> %.1f Mpaths/s" % (a.scene, a.width, a.height, a.spp, a.kernel, a.mode,
+      ctx.last_launch_path_scheduling(), ["%.3f" % m for m in ms], paths / (min(ms) / 1e3) / 1e6))
 ctx.close()

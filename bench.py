@@ -20,7 +20,8 @@ With N > 1 the weak-scaling steps are followed by as many strong-scaling steps:
 the samples of ONE GPU's step dealt to the N ranks (`strong_scaling` in the line).
 
 Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
-FP32 vector peak; `time_to_rmse` (N = 1) is the wall time from a camera reset
+FP32 vector peak (its `traffic` is measured by two rocprofv3 counter passes run
+as child processes, N = 1); `time_to_rmse` (N = 1) is the wall time from a camera reset
 until the image is within RMSE 0.02 of a converged reference; `cpu_baseline`
 times the CPU oracle on this host's cores on a bounded sample of the same
 workload and, when this host has a CPU OpenCL device and the reference's kernel
@@ -51,6 +52,43 @@ def recorded(name, key):
             return json.load(f).get(key)
     except (OSError, ValueError):
         return None
+
+
+def measured_traffic(workload_args, timeout_s=150):
+    """HBM-side bytes of one launch of the render kernel, measured now: FETCH_SIZE and WRITE_SIZE of the same workload in
+    two separate `rocprofv3 --pmc` passes (each a child process running tools/prof_run.py), FETCH_SIZE doubled as gfx950
+    needs for wide reads.  Returns (bytes, text) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_run.py"), "--launches", "1"] + workload_args
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass did not finish within %d s" % (counter, timeout_s)
+            if r.returncode != 0:
+                return None, "the %s pass failed (exit status %d)" % (counter, r.returncode)
+            value = None
+            for f in sorted(glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True)):
+                for row in csv.DictReader(open(f)):
+                    if "bdpt" in row["Kernel_Name"] and "query" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        value = float(row["Counter_Value"])              # the last launch of the run is the measured one
+            if value is None:
+                return None, "the %s pass recorded no render kernel" % counter
+            got[counter] = value
+    total = int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0)
+    return total, ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, of `tools/prof_run.py %s` "
+                   "(the timed launch's workload and launch form); FETCH_SIZE=%.0f KB doubled (gfx950 counts half the bytes of wide "
+                   "reads; an upper bound for narrow ones), WRITE_SIZE=%.0f KB; L2-to-fabric boundary, Infinity Cache hits included"
+                   % (" ".join(workload_args), got["FETCH_SIZE"], got["WRITE_SIZE"]))
 
 
 def reference_on_cpu_opencl(scene, camera, seeds, width, height, frames=16, warmup=2, timeout_s=240):
@@ -119,6 +157,8 @@ def main():
                     help="skip the extra launch of the same frame in STREAM + MEAN mode (the reference's generator and blend)")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the combined mean image of the last step (.npy)")
     ap.add_argument("--dump-strong-image", default=None, help="N > 1: rank 0 saves the combined mean image of the last strong-scaling step (.npy)")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child processes (N = 1); quote the committed figure instead")
     ap.add_argument("--no-time-to-rmse", action="store_true", help="skip the time-to-target-RMSE measurement (N = 1, c2)")
     ap.add_argument("--rmse-target", type=float, default=0.02)
     ap.add_argument("--rmse-ref-spp", type=int, default=16384)
@@ -338,12 +378,23 @@ def main():
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
         achieved = flops / avg_s / 1e12
         traffic = recorded("hbm_traffic.json", "%s/%dx%d" % (args.workload, W, H))
+        traffic_bytes = None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (weak_chunks - 1)
+        traffic_source = None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run")
+        if world == 1 and not args.no_traffic_pass:
+            scene_arg = {"c2": "cornell", "c3": "outdoor", "c4": "soup:%d" % args.soup}[args.workload]
+            live, text = measured_traffic(["--spp", str(SPP), "--kernel", str(variant), "--scene", scene_arg, "--width", str(W), "--height", str(H)])
+            if live is not None:
+                if traffic_bytes is not None:
+                    text += "; profiles/hbm_traffic.json (an earlier session) gives %d" % traffic_bytes
+                traffic_bytes, traffic_source = live, text
+            elif traffic_source is not None:
+                traffic_source = "not measured by this run (%s); " % text + traffic_source
         out["roofline"] = {
             "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
             "frac_reference_formulation": round(flops_ref / avg_s / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-            "traffic": None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (weak_chunks - 1),
-            "traffic_source": None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run"),
+            "traffic": traffic_bytes,
+            "traffic_source": traffic_source,
             "kernel_ms": round(avg_s * 1e3, 3), "flops_per_launch": flops, "flops_per_launch_reference_formulation": flops_ref,
             "rays_traced": rays, "rays_reference_formulation": rays_ref, "paths_full": full, "paths_early": early,
             "flops_per_ray": f_ray, "cull_tests": n_cull, "exact_triangle_tests_after_cull": n_exact,

@@ -10,7 +10,7 @@ O=gpurun_out/${1:-r03}
 rm -rf $O; mkdir -p $O
 step() { echo "== $*"; }
 step bench; timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
-step rocprof-stats; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-stream-line --no-time-to-rmse > $O/bench_under_rocprof.json 2> $O/rocprof.err || { echo "rocprof failed"; tail -5 $O/rocprof.err; exit 1; }
+step rocprof-stats; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-stream-line --no-time-to-rmse --no-traffic-pass > $O/bench_under_rocprof.json 2> $O/rocprof.err || { echo "rocprof failed"; tail -5 $O/rocprof.err; exit 1; }
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 step c3; timeout -k 10 300 python3 bench.py --workload c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/c3.err || { echo "c3 failed"; tail -5 $O/c3.err; exit 1; }
 step c4; timeout -k 10 400 python3 bench.py --workload c4 --no-cpu-baseline --steps 2 > $O/bench_c4.json 2> $O/c4.err || { echo "c4 failed"; tail -5 $O/c4.err; exit 1; }

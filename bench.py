@@ -54,10 +54,9 @@ def recorded(name, key):
         return None
 
 
-def measured_traffic(workload_args, timeout_s=150):
-    """HBM-side bytes of one launch of the render kernel, measured now: FETCH_SIZE and WRITE_SIZE of the same workload in
-    two separate `rocprofv3 --pmc` passes (each a child process running tools/prof_run.py), FETCH_SIZE doubled as gfx950
-    needs for wide reads.  Returns (bytes, text) or (None, reason)."""
+def counter_pass(workload_args, counters, timeout_s=150):
+    """One `rocprofv3 --pmc` pass (a child process running tools/prof_run.py on the given workload): the named hardware
+    counters of the run's last render launch.  Returns (dict, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -65,30 +64,72 @@ def measured_traffic(workload_args, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 is not on PATH"
-    got = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
-                   sys.executable, os.path.join(ROOT, "tools", "prof_run.py"), "--launches", "1"] + workload_args
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "--",
+               sys.executable, os.path.join(ROOT, "tools", "prof_run.py"), "--launches", "1"] + workload_args
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, "the pass for %s did not finish within %d s" % (" ".join(counters), timeout_s)
+        if r.returncode != 0:
+            return None, "the pass for %s failed (exit status %d)" % (" ".join(counters), r.returncode)
+        got = {}
+        for f in sorted(glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)):
+            for row in csv.DictReader(open(f)):
+                if "bdpt" in row["Kernel_Name"] and "query" not in row["Kernel_Name"]:
+                    got[row["Counter_Name"]] = float(row["Counter_Value"])     # rows come in launch order: the last launch stays
+        ms = [ln for ln in r.stdout.splitlines() if ln.startswith("scene=")]
+        if ms:
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                return None, "the %s pass did not finish within %d s" % (counter, timeout_s)
-            if r.returncode != 0:
-                return None, "the %s pass failed (exit status %d)" % (counter, r.returncode)
-            value = None
-            for f in sorted(glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True)):
-                for row in csv.DictReader(open(f)):
-                    if "bdpt" in row["Kernel_Name"] and "query" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        value = float(row["Counter_Value"])              # the last launch of the run is the measured one
-            if value is None:
-                return None, "the %s pass recorded no render kernel" % counter
-            got[counter] = value
+                got["_kernel_ms"] = float(ms[-1].split("[")[1].split("]")[0].split(",")[-1].strip(" '"))
+            except (IndexError, ValueError):
+                pass
+    missing = [c for c in counters if c not in got]
+    if missing:
+        return None, "the pass recorded no %s for the render kernel" % " ".join(missing)
+    return got, None
+
+
+def measured_traffic(workload_args):
+    """HBM-side bytes of one launch of the render kernel, measured now: FETCH_SIZE and WRITE_SIZE of the same workload in
+    two separate counter passes, FETCH_SIZE doubled as gfx950 needs for wide reads.  Returns (bytes, text) or (None, reason)."""
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        c, why = counter_pass(workload_args, [counter])
+        if c is None:
+            return None, why
+        got[counter] = c[counter]
     total = int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0)
     return total, ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, of `tools/prof_run.py %s` "
                    "(the timed launch's workload and launch form); FETCH_SIZE=%.0f KB doubled (gfx950 counts half the bytes of wide "
                    "reads; an upper bound for narrow ones), WRITE_SIZE=%.0f KB; L2-to-fabric boundary, Infinity Cache hits included"
                    % (" ".join(workload_args), got["FETCH_SIZE"], got["WRITE_SIZE"]))
+
+
+def measured_executed(workload_args):
+    """The hardware's view of one launch, measured now in one counter pass: FP32 vector operations the lanes performed
+    ((2 FMA + MUL + ADD wave-instructions) x 64 x lane utilisation) per second, and what the SIMDs did meanwhile.
+    Packed two-wide instructions are billed once, so a kernel that uses them performs more than this says."""
+    c, why = counter_pass(workload_args, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_FMA_F32",
+                                          "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"])
+    if c is None:
+        return None, why
+    clocks = c["GRBM_GUI_ACTIVE"] / 8.0                                   # the counter adds up the eight dies
+    ms = c.get("_kernel_ms", clocks / 2.4e6)
+    util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    flops = (2 * c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) * 64 * util
+    return {
+        "source": "measured by this run: one rocprofv3 --pmc pass of `tools/prof_run.py %s`" % " ".join(workload_args),
+        "kernel_ms_under_profiler": round(ms, 2),
+        "valu_wave_insts": c["SQ_INSTS_VALU"],
+        "fp32_arith_fraction_of_valu": round((c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / c["SQ_INSTS_VALU"], 3),
+        "lane_utilisation": round(util, 3),
+        "executed_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+        "executed_frac_of_157.3": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 3),
+        "simd_cycles_per_valu_inst": round(1024 * clocks / c["SQ_INSTS_VALU"], 2),
+        "wavefronts_per_simd_mean": round(c["SQ_WAVE_CYCLES"] * 4.0 / (1024 * clocks), 2),
+        "wave_cycles_waiting_fraction": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+    }, None
 
 
 def reference_on_cpu_opencl(scene, camera, seeds, width, height, frames=16, warmup=2, timeout_s=240):
@@ -382,7 +423,8 @@ def main():
         traffic_source = None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run")
         if world == 1 and not args.no_traffic_pass:
             scene_arg = {"c2": "cornell", "c3": "outdoor", "c4": "soup:%d" % args.soup}[args.workload]
-            live, text = measured_traffic(["--spp", str(SPP), "--kernel", str(variant), "--scene", scene_arg, "--width", str(W), "--height", str(H)])
+            workload_args = ["--spp", str(SPP), "--kernel", str(variant), "--scene", scene_arg, "--width", str(W), "--height", str(H)]
+            live, text = measured_traffic(workload_args)
             if live is not None:
                 if traffic_bytes is not None:
                     text += "; profiles/hbm_traffic.json (an earlier session) gives %d" % traffic_bytes
@@ -406,6 +448,14 @@ def main():
         executed = recorded("pmc_summary.json", "%s/%s" % (args.workload, variant_name))
         if executed is not None:
             out["roofline"]["executed"] = executed       # hardware view of the same launch, from committed PMC passes
+        if world == 1 and not args.no_traffic_pass:
+            live, why = measured_executed(workload_args)
+            if live is not None:
+                if executed is not None:
+                    live["committed_passes"] = executed                  # the fuller set of counters, from an earlier session
+                out["roofline"]["executed"] = live
+            elif executed is not None:
+                executed["not_measured_by_this_run"] = why
         # the same launch against the HBM roofline, to show that it is not the one that binds:
         # 16 B accumulator read + 16 B write + 4 B seed word per pixel per launch, whatever spp is
         hbm = W * H * 36 / avg_s / 1e9

@@ -994,17 +994,17 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     bool pooled = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && ctx->path_scheduling == BDPT_PATHS_POOLED &&
                   bdpt_pool_supported(K, variant);
     if (pooled) {
-        if (ctx->launch_chunks == 0) {                   /* long runs keep a pool full; few runs keep the state small */
-            const int chunks = std::max(1, std::min(BDPT_POOL_AUTO_CHUNKS, spp / BDPT_POOL_AUTO_CHUNK_MIN_SPP));
-            K.chunk_spp = (spp + chunks - 1) / chunks;
-            K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
-        }
-        size_t bytes = bdpt_pool_state_bytes(K, variant, K.n_chunks);
-        while (K.n_chunks > 1 && bytes > ctx->order_scratch_limit) {
-            const int chunks = K.n_chunks / 2;
-            K.chunk_spp = (spp + chunks - 1) / chunks;
-            K.n_chunks = (spp + K.chunk_spp - 1) / K.chunk_spp;
-            bytes = bdpt_pool_state_bytes(K, variant, K.n_chunks);
+        int n_chunks = K.n_chunks, chunk_spp = K.chunk_spp;
+        auto cut = [&](int chunks) {
+            chunk_spp = (spp + chunks - 1) / chunks;
+            n_chunks = (spp + chunk_spp - 1) / chunk_spp;
+        };
+        if (ctx->launch_chunks == 0)                     /* long runs keep a pool full; few runs keep the state small */
+            cut(std::max(1, std::min(BDPT_POOL_AUTO_CHUNKS, spp / BDPT_POOL_AUTO_CHUNK_MIN_SPP)));
+        size_t bytes = bdpt_pool_state_bytes(K, variant, n_chunks);
+        while (n_chunks > 1 && bytes > ctx->order_scratch_limit) {
+            cut(n_chunks / 2);
+            bytes = bdpt_pool_state_bytes(K, variant, n_chunks);
         }
         if (bytes > ctx->pool_state_bytes && bytes <= ctx->order_scratch_limit) {
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
@@ -1019,8 +1019,8 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
                 else { ctx->d_pool_state = nullptr; (void)hipGetLastError(); }
             }
         }
-        if (bytes == 0 || bytes > ctx->pool_state_bytes) pooled = false;
-        else K.pool_state = ctx->d_pool_state;
+        if (bytes == 0 || bytes > ctx->pool_state_bytes) pooled = false;     /* the per-lane launch keeps its own cut */
+        else { K.pool_state = ctx->d_pool_state; K.n_chunks = n_chunks; K.chunk_spp = chunk_spp; }
     }
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));

@@ -1392,6 +1392,7 @@ bool bdpt_pool_supported(const bdpt_kargs &K, int variant)
 {
     if (variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2) return false;
     if (K.sampler != BDPT_SAMPLER_LAMBERT_CONE || K.tile_stride > 1) return false;
+    if ((uint32_t)K.scene.n_surfaces > BDPT_POOL_SURF_MASK || K.max_l > 255) return false;     /* what a slot's misc word has room for */
     if (variant == BDPT_KERNEL_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return false;
     return bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
 }

@@ -255,9 +255,20 @@ int bdpt_last_launch_chunks(const bdpt_ctx *ctx);
  *           A pixel still has one sample in flight at a time, in the launch's order, so generator streams, running
  *           means and sums are untouched.  For the kernel variants that keep the scene in LDS and the reference's live
  *           sampler; other launches run PER_LANE whatever is asked (bdpt_last_launch_path_scheduling tells).
- * AUTO:     PER_LANE.
+ * BY_CLASS: a wavefront owns 16 x 8 pixels and every round runs ONE WHOLE SAMPLE for up to 64 of them, chosen so that
+ *           their light subpaths end at about the same vertex: how many vertices roulette allows a sample (:787-788)
+ *           follows from the generator word the sample starts with, so the pixels are sorted by the class of their next
+ *           sample and the round takes the window of classes that wastes the fewest lane-steps.  A pixel's samples
+ *           are still taken one after the other in index order, which is what the reference's own mode (sequential
+ *           generator, running mean) requires; nothing is allocated.  For launches in index order (BDPT_ORDER_INDEX, or
+ *           any mode that does not allow another order) of the small-scene kernel variants with at most five light-
+ *           subpath vertices and no interleaved tile split; other launches run PER_LANE whatever is asked.  The work
+ *           counter of rays (bdpt_read_counters) of a sliced BDPT_RNG_STREAM launch is lower than a PER_LANE launch's:
+ *           a pixel whose eye ray ends the path (:645-656) is traced once per launch, not once per run.
+ *           1080p Cornell box, 1024 samples, sequential generator and running mean: 118 ms against 134 ms PER_LANE.
+ * AUTO:     BY_CLASS for the launches that allow it from 32 samples per pixel on, else PER_LANE.
  * No reference counterpart. */
-enum { BDPT_PATHS_AUTO = 0, BDPT_PATHS_PER_LANE = 1, BDPT_PATHS_POOLED = 2 };
+enum { BDPT_PATHS_AUTO = 0, BDPT_PATHS_PER_LANE = 1, BDPT_PATHS_POOLED = 2, BDPT_PATHS_BY_CLASS = 3 };
 int bdpt_set_path_scheduling(bdpt_ctx *ctx, int mode);
 int bdpt_last_launch_path_scheduling(const bdpt_ctx *ctx);
 /* A run of a sliced launch waits for the run before it on the same tile.  That wait always ends unless something

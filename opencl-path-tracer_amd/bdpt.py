@@ -30,7 +30,7 @@ LIGHT_ORIGIN_SELF, LIGHT_ORIGIN_NONE = 0, 1
 FALLOFF_INV_SQ, FALLOFF_INV_SQ_PLUS_C = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_LDS, KERNEL_TILED, KERNEL_LDS2 = 0, 1, 3, 4, 5
-PATHS_AUTO, PATHS_PER_LANE, PATHS_POOLED = 0, 1, 2
+PATHS_AUTO, PATHS_PER_LANE, PATHS_POOLED, PATHS_BY_CLASS = 0, 1, 2, 3
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
 SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE, SAMPLER_LAMBERT_IMP = 0, 1, 2, 3
 INTEGRATOR_BIDIRECTIONAL, INTEGRATOR_PATH_TRACE = 0, 1
@@ -437,7 +437,8 @@ class Context:
         self._check(lib.bdpt_set_launch_chunks(self._h, chunks))
 
     def set_path_scheduling(self, mode):
-        """PATHS_PER_LANE or PATHS_POOLED (a wavefront's paths sorted by phase); never changes a result."""
+        """PATHS_PER_LANE, PATHS_POOLED (a wavefront's paths sorted by phase), PATHS_BY_CLASS (a wavefront's pixels sorted by
+        the length of their next sample) or PATHS_AUTO (the library chooses); never changes a result."""
         self._check(lib.bdpt_set_path_scheduling(self._h, mode))
 
     def last_launch_path_scheduling(self):

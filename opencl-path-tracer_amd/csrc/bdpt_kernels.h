@@ -30,6 +30,12 @@ bool bdpt_pool_supported(const bdpt_kargs &K, int variant);
 size_t bdpt_pool_state_bytes(const bdpt_kargs &K, int variant, int chunks);
 hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream);
 
+/* Launches that take every pixel's samples in index order, with a wavefront's pixels sorted by the class of their next
+ * sample (bdpt_class_pool.h): a wavefront owns BDPT_CPOOL_W x BDPT_CPOOL_ROWS pixels and runs one whole sample per round for 64 of them whose light
+ * subpaths roulette will cut to about the same length.  Needs no memory beyond the per-pixel launches'.  variant: BDPT_KERNEL_DIRECT, _LDS or _LDS2. */
+bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant);
+hipError_t bdpt_launch_class_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream);
+
 /* The reference's older unidirectional kernel (kernel0.cl:872-1001): spp samples per pixel of the region in one launch. */
 hipError_t bdpt_launch_path_trace(const bdpt_kargs &K, bool aov, hipStream_t stream);
 

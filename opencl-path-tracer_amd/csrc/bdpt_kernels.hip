@@ -1288,6 +1288,7 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 }  // namespace bdpt
 
 #include "bdpt_pool.h"
+#include "bdpt_class_pool.h"
 
 /* ---- launch wrappers ------------------------------------------------------ */
 
@@ -1295,7 +1296,7 @@ __global__ void bdpt_clmath_kernel(int op, const double *in, double *out, int n)
 static dim3 pixel_grid(const bdpt_kargs &K)
 {
     if (K.pool_rows) {                                   /* whole region only: see bdpt_pool_supported */
-        const int block_w = (K.block >> 6) * BDPT_POOL_W;
+        const int block_w = (K.block >> 6) * K.pool_w;
         return dim3((K.rw + block_w - 1) / block_w, (K.rh + K.pool_rows - 1) / K.pool_rows);
     }
     const int block_w = K.block >> 3;
@@ -1429,6 +1430,7 @@ static hipError_t launch_pool(bdpt_kargs K, bool aov, bool count, hipStream_t st
     const int nw = pool_waves_per_workgroup(K, variant);
     if (nw == 0) return hipErrorInvalidValue;
     K.block = 64 * nw;
+    K.pool_w = BDPT_POOL_W;
     K.pool_rows = BDPT_POOL_ROWS;
     const size_t lds = bdpt_lds_scene_bytes(K.scene, MODE == bdpt::MODE_LDS2) + (size_t)nw * BDPT_POOL_WAVE_F4 * sizeof(float4);
     dim3 grid;
@@ -1449,6 +1451,69 @@ hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool cou
 {
     if (!bdpt_pool_supported(K, variant)) return hipErrorInvalidValue;
     return variant == BDPT_KERNEL_LDS2 ? launch_pool<bdpt::MODE_LDS2>(K, aov, count, stream) : launch_pool<bdpt::MODE_LDS>(K, aov, count, stream);
+}
+
+/* Pixels sorted by the class of their next sample (bdpt_class_pool.h): launches that take every pixel's samples in index
+ * order, with the per-pixel kernels' workgroup shapes (one wavefront where 24 workgroups fit a compute unit, else two). */
+bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant)
+{
+    if (variant != BDPT_KERNEL_DIRECT && variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2) return false;
+    if (K.reorder != 0 || K.tile_stride > 1 || K.max_l > BDPT_CPOOL_MAX_CLASS) return false;
+    if (variant == BDPT_KERNEL_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return false;
+    return variant == BDPT_KERNEL_DIRECT || bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
+}
+
+/* threads per workgroup and bytes of LDS of such a launch */
+static void class_pool_shape(const bdpt_kargs &K, int variant, int &block, size_t &lds)
+{
+    const size_t pool = (size_t)BDPT_CPOOL_WAVE_F4 * sizeof(float4);
+    lds = 0;
+    block = 64;
+    if (variant != BDPT_KERNEL_DIRECT) {
+        lds = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);
+        const size_t park = (size_t)64 * BDPT_PARK_F4 * sizeof(float4);   /* the lanes' parked eye vertices, behind the scene */
+        block = launch_block(lds, park + pool);
+        lds += park * (block / 64);
+    }
+    lds += pool * (block / 64);
+}
+
+template <int MODE>
+static hipError_t launch_class_pool(bdpt_kargs K, bool aov, bool count, hipStream_t stream)
+{
+    if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
+    size_t lds = 0;
+    class_pool_shape(K, MODE == bdpt::MODE_LDS2 ? BDPT_KERNEL_LDS2 : MODE == bdpt::MODE_LDS ? BDPT_KERNEL_LDS : BDPT_KERNEL_DIRECT, K.block, lds);
+    K.pool_w = BDPT_CPOOL_W;
+    K.pool_rows = BDPT_CPOOL_ROWS;
+    dim3 grid;
+    const dim3 block(K.block);
+    const hipError_t e = sliced_grid(K, grid, stream);
+    if (e != hipSuccess) return e;
+    if (grid.x == 0) return hipSuccess;
+    const bool alt = K.sampler != BDPT_SAMPLER_LAMBERT_CONE;
+#define BDPT_LAUNCH(A, C, X) hipLaunchKernelGGL((bdpt::bdpt_class_pool_kernel<A, C, MODE, X>), grid, block, lds, stream, K)
+    if (alt) {
+        if (aov && count) BDPT_LAUNCH(true, true, true);
+        else if (aov) BDPT_LAUNCH(true, false, true);
+        else if (count) BDPT_LAUNCH(false, true, true);
+        else BDPT_LAUNCH(false, false, true);
+    } else {
+        if (aov && count) BDPT_LAUNCH(true, true, false);
+        else if (aov) BDPT_LAUNCH(true, false, false);
+        else if (count) BDPT_LAUNCH(false, true, false);
+        else BDPT_LAUNCH(false, false, false);
+    }
+#undef BDPT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t bdpt_launch_class_pool(const bdpt_kargs &K, int variant, bool aov, bool count, hipStream_t stream)
+{
+    if (!bdpt_class_pool_supported(K, variant)) return hipErrorInvalidValue;
+    if (variant == BDPT_KERNEL_LDS2) return launch_class_pool<bdpt::MODE_LDS2>(K, aov, count, stream);
+    if (variant == BDPT_KERNEL_LDS) return launch_class_pool<bdpt::MODE_LDS>(K, aov, count, stream);
+    return launch_class_pool<bdpt::MODE_DIRECT>(K, aov, count, stream);
 }
 
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K_in, bool aov, bool count, hipStream_t stream)

@@ -94,6 +94,13 @@ struct bdpt_dev_scene {
 #define BDPT_POOL_ROWS 6
 #endif
 #define BDPT_POOL_GLOBAL_F4 4
+/* launches that sort a wavefront's pixels by the class of their next sample (bdpt_class_pool.h): BDPT_CPOOL_W x BDPT_CPOOL_ROWS pixels per wavefront */
+#ifndef BDPT_CPOOL_W
+#define BDPT_CPOOL_W 16
+#endif
+#ifndef BDPT_CPOOL_ROWS
+#define BDPT_CPOOL_ROWS 8
+#endif
 
 struct bdpt_kargs {
     bdpt_dev_scene scene;
@@ -131,6 +138,7 @@ struct bdpt_kargs {
     int block;                  /* threads per workgroup, 64 or 128: one 8x8-pixel tile per wavefront, side by side (set by the launcher) */
     float4 *pool_state;         /* pooled launches: BDPT_POOL_GLOBAL_F4 float4 per pixel slot, one region per run of a tile and wavefront */
     const float *xt_tab, *yt_tab;   /* the normalised screen coordinate of every pixel column and row (kernel0.cl:600-604) */
+    int pool_w;                 /* with pool_rows: pixels per wavefront of a pooled launch, pool_w x pool_rows */
     int pool_rows;              /* 0: one lane per pixel.  Else the launch sorts its paths by phase (bdpt_pool.h): a wavefront owns 16 x pool_rows pixels, block / 64 wavefronts side by side */
     int num_samples;            /* imgDesc.numSamples before the first sample */
     int spp;

@@ -466,27 +466,33 @@ def main():
         # region): samples are taken in index order there, so the wavefronts pay for roulette divergence
         if not args.no_stream_line and world == 1:
             ctx.set_params(bdpt.default_params(kernel_variant=args.kernel))
-            ctx.set_camera(scene.camera)
-            ctx.render(SPP)
-            ctx.num_samples = 0
-            ctx.render(SPP)
-            out["stream_mode"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
-                                  "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
-                                  "what": "rng_mode STREAM + accum_mode MEAN: the reference's own generator and running mean, one launch"}
-            # the same launch with a wavefront's paths sorted by phase (bdpt_set_path_scheduling POOLED): built to take
-            # the roulette divergence out of this mode; reported beside the per-lane launch, whichever is faster
-            if ctx.last_launch_variant() in (bdpt.KERNEL_LDS, bdpt.KERNEL_LDS2):
-                ctx.set_path_scheduling(bdpt.PATHS_POOLED)
+            names = {bdpt.PATHS_PER_LANE: "per_lane", bdpt.PATHS_POOLED: "pooled_by_phase", bdpt.PATHS_BY_CLASS: "by_class"}
+
+            def stream_launch(sched):
+                """one warm-up and one measured launch of the frame in the reference's mode; None if it ran another way"""
+                ctx.set_path_scheduling(sched)
                 ctx.set_camera(scene.camera)
                 ctx.render(SPP)
                 ctx.num_samples = 0
                 ctx.render(SPP)
-                if ctx.last_launch_path_scheduling() == bdpt.PATHS_POOLED:
-                    out["stream_mode"]["pooled"] = {"kernel_ms": round(ctx.last_launch_ms(), 3),
-                                                    "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
-                                                    "runs_per_tile": ctx.last_launch_chunks(),
-                                                    "what": "96 pixels per wavefront, one phase per round for up to 64 of their paths"}
-                ctx.set_path_scheduling(bdpt.PATHS_AUTO)
+                ran = ctx.last_launch_path_scheduling()
+                if sched != bdpt.PATHS_AUTO and ran != sched:
+                    return None
+                return {"kernel_ms": round(ctx.last_launch_ms(), 3),
+                        "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
+                        "path_scheduling": names[ran], "runs_per_tile": ctx.last_launch_chunks()}
+
+            # as the library runs it when left to itself (pixels of a wavefront sorted by the roulette class of their next
+            # sample where the launch allows it), then with each way of putting paths on lanes asked for by name
+            line = stream_launch(bdpt.PATHS_AUTO)
+            line["what"] = "rng_mode STREAM + accum_mode MEAN: the reference's own generator and running mean, one launch, path scheduling left to the library"
+            for sched in (bdpt.PATHS_PER_LANE, bdpt.PATHS_BY_CLASS, bdpt.PATHS_POOLED):
+                sub = stream_launch(sched)
+                if sub is not None:
+                    del sub["path_scheduling"]
+                    line[names[sched]] = sub
+            ctx.set_path_scheduling(bdpt.PATHS_AUTO)
+            out["stream_mode"] = line
             ctx.set_params(bench_params)
 
     # The second half of the headline metric: wall time from a camera reset until the accumulated image is within

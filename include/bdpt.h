@@ -240,7 +240,7 @@ int bdpt_set_tile_interleave(bdpt_ctx *ctx, int tile_w, int tile_h, int stride, 
 /* How a render call of many samples is run: as `chunks` runs of spp/chunks samples per workgroup tile (8x8 or 16x8 pixels), each run
  * a workgroup of its own that picks up the tile's pixel state where the run before left it, so that the launch
  * does not end with the GPU draining behind a few long workgroups.  The result is bit-identical for any value.
- * 0 (the default): chosen per launch (up to 16 runs, their length set by how long a sample of the scene took on the last call; one sample per run for scenes of many
+ * 0 (the default): chosen per launch (up to 16 runs, 32 for BDPT_PATHS_BY_CLASS launches, their length set by how long a sample of the scene took on the last call; one sample per run for scenes of many
  * triangles); 1: one run. */
 int bdpt_set_launch_chunks(bdpt_ctx *ctx, int chunks);
 /* runs per tile the last render call asked its launch for (1 = unsliced) */

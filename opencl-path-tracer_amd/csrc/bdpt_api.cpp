@@ -935,6 +935,13 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     if (variant == BDPT_KERNEL_AUTO)
         variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && K.scene.n_triangles <= BDPT_CULL_MAX_TRIANGLES && !ctx->auto_tiled) ? BDPT_KERNEL_TILED
                   : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
+    /* Pixels sorted by the class of their next sample (bdpt_class_pool.h): launches in index order.  Left to itself the
+     * library runs them so from BDPT_CPOOL_AUTO_MIN_SPP samples on (1080p Cornell box, sequential generator, running
+     * mean: 1 sample 0.25 against 0.20 ms, 4 samples 0.79 against 0.89, 64 samples 9.3 against 9.6, 1024 samples 118
+     * against 134).  Its runs cost less to start than the per-lane kernels' (the image is updated in place), so a
+     * launch may be cut into twice as many. */
+    const bool by_class = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && bdpt_class_pool_supported(K, variant) &&
+                          (ctx->path_scheduling == BDPT_PATHS_BY_CLASS || (ctx->path_scheduling == BDPT_PATHS_AUTO && spp >= BDPT_CPOOL_AUTO_MIN_SPP));
     /* Sliced launch (slice_begin in bdpt_kernels.hip): runs short enough that the launch does not end with a long
      * drain, long enough that the per-run reload of the pixel state does not show (1080p Cornell box: 64 samples
      * 10.4 -> 9.8 ms as 8 runs, 256 samples 47.5 -> 42.2 ms as 16, 1024 samples 175 -> 158 ms as 16, no gain from
@@ -949,7 +956,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
             int min_spp = variant == BDPT_KERNEL_TILED ? 1 : BDPT_AUTO_CHUNK_MIN_SPP;
             if (ctx->ms_per_pixel_sample > 0.0)
                 min_spp = (int)std::min(64.0, std::max(1.0, std::ceil(3.0 * BDPT_RUN_COST_MS_PER_PIXEL / ctx->ms_per_pixel_sample)));
-            chunks = std::min(BDPT_AUTO_CHUNKS, spp / min_spp);
+            chunks = std::min(by_class ? 2 * BDPT_AUTO_CHUNKS : BDPT_AUTO_CHUNKS, spp / min_spp);
         }
         chunks = std::max(1, std::min(chunks, spp));
         K.chunk_spp = (spp + chunks - 1) / chunks;
@@ -1031,12 +1038,6 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         if (bytes == 0 || bytes > ctx->pool_state_bytes) pooled = false;     /* the per-lane launch keeps its own cut */
         else { K.pool_state = ctx->d_pool_state; K.n_chunks = n_chunks; K.chunk_spp = chunk_spp; }
     }
-    /* Pixels sorted by the class of their next sample (bdpt_class_pool.h): launches in index order.  Left to itself the
-     * library runs them so from BDPT_CPOOL_AUTO_MIN_SPP samples on (1080p Cornell box, sequential generator, running
-     * mean: 1 sample 0.25 against 0.20 ms, 4 samples 0.79 against 0.89, 64 samples 9.3 against 9.6, 1024 samples 118
-     * against 134). */
-    const bool by_class = !pooled && ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && bdpt_class_pool_supported(K, variant) &&
-                          (ctx->path_scheduling == BDPT_PATHS_BY_CLASS || (ctx->path_scheduling == BDPT_PATHS_AUTO && spp >= BDPT_CPOOL_AUTO_MIN_SPP));
     if (ctx->counters_on) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BDPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     ctx->last_path_scheduling = pooled ? BDPT_PATHS_POOLED : by_class ? BDPT_PATHS_BY_CLASS : BDPT_PATHS_PER_LANE;

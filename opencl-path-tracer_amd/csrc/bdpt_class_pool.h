@@ -39,6 +39,7 @@ namespace bdpt {
  * words), the 64 slot numbers of a round */
 #define BDPT_CPOOL_LANE_WORDS (2 * BDPT_CPOOL_PER_LANE)
 #define BDPT_CPOOL_WAVE_F4 ((64 * BDPT_CPOOL_LANE_WORDS + 3) / 4 + 16)
+#define BDPT_CPOOL_BLOCK_MAX 256          /* threads per workgroup, at most */
 #define BDPT_CPOOL_MAX_CLASS 5            /* launches with longer light subpaths run one lane per pixel */
 
 static_assert(BDPT_CPOOL_SLOTS % 64 == 0 && BDPT_CPOOL_PER_LANE <= 8, "a lane looks after BDPT_CPOOL_PER_LANE slots");
@@ -46,7 +47,7 @@ static_assert(BDPT_CPOOL_SLOTS % 64 == 0 && BDPT_CPOOL_PER_LANE <= 8, "a lane lo
 /* slot word: class of the pixel's next sample (bits 0-7; 0 = no more samples in this run) | samples taken in this run << 8 */
 
 template <bool AOV, bool COUNT, int MODE, bool ALT>
-__global__ __launch_bounds__(BDPT_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
+__global__ __launch_bounds__(BDPT_CPOOL_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
 void bdpt_class_pool_kernel(const bdpt_kargs K)
 {
     constexpr int PER = BDPT_CPOOL_PER_LANE;

@@ -1463,19 +1463,22 @@ bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant)
     return variant == BDPT_KERNEL_DIRECT || bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
 }
 
-/* threads per workgroup and bytes of LDS of such a launch */
+/* Threads per workgroup and bytes of LDS of such a launch: the fewest wavefronts per workgroup (they share one copy of
+ * the scene) with which 24 wavefronts, six per SIMD, fit the 160 KB of a compute unit. */
 static void class_pool_shape(const bdpt_kargs &K, int variant, int &block, size_t &lds)
 {
     const size_t pool = (size_t)BDPT_CPOOL_WAVE_F4 * sizeof(float4);
-    lds = 0;
-    block = 64;
-    if (variant != BDPT_KERNEL_DIRECT) {
-        lds = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);
-        const size_t park = (size_t)64 * BDPT_PARK_F4 * sizeof(float4);   /* the lanes' parked eye vertices, behind the scene */
-        block = launch_block(lds, park + pool);
-        lds += park * (block / 64);
+    if (variant == BDPT_KERNEL_DIRECT) {
+        block = 64;
+        lds = pool;
+        return;
     }
-    lds += pool * (block / 64);
+    const size_t scene = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);
+    const size_t park = (size_t)64 * BDPT_PARK_F4 * sizeof(float4);       /* the lanes' parked eye vertices, behind the scene */
+    int nw = 1;
+    while (nw < BDPT_CPOOL_BLOCK_MAX / 64 && (24 / nw) * (scene + nw * (park + pool)) > 160 * 1024) nw *= 2;
+    block = 64 * nw;
+    lds = scene + nw * (park + pool);
 }
 
 template <int MODE>

@@ -2,7 +2,7 @@
 bench workload (Cornell, 1920x1080 unless overridden) through the C-ABI, no torch.
 
     python3 tools/prof_run.py [--spp 128] [--launches 2] [--scene cornell|soup:N|outdoor|planes]
-                              [--width W --height H] [--mode strided|stream] [--kernel K] [--chunks C] [--paths 1|2]
+                              [--width W --height H] [--mode strided|stream] [--kernel K] [--chunks C] [--paths 0..3]
 """
 import argparse
 import os
@@ -21,7 +21,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mode", default="strided")
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--chunks", type=int, default=0, help="bdpt_set_launch_chunks (0 = automatic, 1 = unsliced)")
-ap.add_argument("--paths", type=int, default=0, help="bdpt_set_path_scheduling (1 = one lane per pixel, 2 = pooled)")
+ap.add_argument("--paths", type=int, default=0, help="bdpt_set_path_scheduling (0 = the library chooses, 1 = one lane per pixel, 2 = paths pooled by phase, 3 = pixels sorted by the class of their next sample)")
 ap.add_argument("--order-scratch", type=int, default=-1, help="bdpt_set_order_scratch_limit in MiB (-1 = the default)")
 a = ap.parse_args()
 

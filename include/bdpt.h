@@ -263,8 +263,9 @@ int bdpt_last_launch_chunks(const bdpt_ctx *ctx);
  *           generator, running mean) requires; nothing is allocated.  For launches in index order (BDPT_ORDER_INDEX, or
  *           any mode that does not allow another order) of the small-scene kernel variants with at most five light-
  *           subpath vertices and no interleaved tile split; other launches run PER_LANE whatever is asked.  The work
- *           counter of rays (bdpt_read_counters) of a sliced BDPT_RNG_STREAM launch is lower than a PER_LANE launch's:
- *           a pixel whose eye ray ends the path (:645-656) is traced once per launch, not once per run.
+ *           counters of rays and primitive tests (bdpt_read_counters) of a sliced BDPT_RNG_STREAM launch are lower than
+ *           a PER_LANE launch's: a pixel whose eye ray ends the path (:645-656) is traced once per launch, not once per
+ *           run.
  *           1080p Cornell box, 1024 samples, sequential generator and running mean: 118 ms against 134 ms PER_LANE.
  * AUTO:     BY_CLASS for the launches that allow it from 32 samples per pixel on, else PER_LANE.
  * No reference counterpart. */

@@ -126,10 +126,15 @@ enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
  * LDS2:   scene in LDS as for LDS (cull records included, so about 130 triangles at most); every
  *         triangle first gets a cheap conservative test from all lanes together, and each lane
  *         then runs the reference's test only on the one or two triangles it could not rule out.
- * AUTO:   TILED when the scene does not fit LDS2 or when enough of its triangles are small
- *         against the scene for the bounding spheres to pay (estimated at upload), else LDS2
- *         (LDS for a scene without triangles). */
-enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, /* 2: a variant that was removed */ BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5 };
+ * BVH:    a hierarchy of boxes over the same bounding spheres (built at scene upload), walked by
+ *         every lane for itself, nearest boxes first: a ray meets the few triangles near its line
+ *         instead of all of them.  The reference's in-order walk keeps the nearest hit and among
+ *         equally near ones the lowest index; the walk keeps exactly that one (any scene size;
+ *         refused for scenes with more than 1024 triangles too thin for a bounding sphere).
+ * AUTO:   BVH (TILED if the scene cannot have a hierarchy) when the scene does not fit LDS2 or
+ *         when enough of its triangles are small against the scene for the bounding spheres to
+ *         pay (estimated at upload), else LDS2 (LDS for a scene without triangles). */
+enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, /* 2: a variant that was removed */ BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5, BDPT_KERNEL_BVH = 6 };
 
 typedef struct bdpt_params {
     int32_t max_light_bounces;  /* maxL, kernel0.cl:683 (5) */

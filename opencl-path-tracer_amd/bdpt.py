@@ -29,7 +29,7 @@ RNG_STREAM, RNG_STRIDED = 0, 1
 LIGHT_ORIGIN_SELF, LIGHT_ORIGIN_NONE = 0, 1
 FALLOFF_INV_SQ, FALLOFF_INV_SQ_PLUS_C = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
-KERNEL_AUTO, KERNEL_DIRECT, KERNEL_LDS, KERNEL_TILED, KERNEL_LDS2 = 0, 1, 3, 4, 5
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_LDS, KERNEL_TILED, KERNEL_LDS2, KERNEL_BVH = 0, 1, 3, 4, 5, 6
 PATHS_AUTO, PATHS_PER_LANE, PATHS_POOLED, PATHS_BY_CLASS = 0, 1, 2, 3
 ORDER_AUTO, ORDER_INDEX, ORDER_ROULETTE_CLASS, ORDER_ADAPTIVE = 0, 1, 2, 3
 SAMPLER_LAMBERT_CONE, SAMPLER_HEMISPHERE, SAMPLER_REFLECTIVE, SAMPLER_LAMBERT_IMP = 0, 1, 2, 3

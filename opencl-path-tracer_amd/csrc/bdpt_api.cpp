@@ -24,6 +24,7 @@
 #include "../../include/bdpt_clmath.h"
 #include "bdpt_ctx_internal.h"
 #include "bdpt_kernels.h"
+#include "bdpt_bvh.h"
 #include "bdpt_layout.h"
 
 /* memory a context may take for the class order of a launch unless told otherwise (bdpt_set_order_scratch_limit) */
@@ -61,6 +62,11 @@ struct bdpt_ctx {
     int cull_f4 = 0;
     uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32] = {};
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
+    /* hierarchy over the triangles' bounding spheres (bdpt_bvh.h), built by every scene upload that has triangles */
+    float4 *d_bvh_nodes = nullptr, *d_bvh_leaf_sph = nullptr;
+    uint32_t *d_bvh_leaf_tri = nullptr, *d_bvh_brute = nullptr;
+    int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0;
+    bool have_bvh = false;              /* false: the scene cannot have one (bdpt_bvh_build), BDPT_KERNEL_BVH is refused */
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
     float4 *d_accum = nullptr;
@@ -282,6 +288,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_tri_cull); dev_free(ctx->d_surf);
     dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
+    dev_free(ctx->d_bvh_nodes); dev_free(ctx->d_bvh_leaf_sph); dev_free(ctx->d_bvh_leaf_tri); dev_free(ctx->d_bvh_brute);
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
     dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters); dev_free(ctx->d_slice_sync); dev_free(ctx->d_slice_cursor);
@@ -340,7 +347,7 @@ int bdpt_set_params(bdpt_ctx *ctx, const bdpt_params *p)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown connection_falloff");
     if (p->accum_mode != BDPT_ACCUM_MEAN && p->accum_mode != BDPT_ACCUM_SUM)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown accum_mode");
-    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_LDS2 || p->kernel_variant == 2)
+    if (p->kernel_variant < BDPT_KERNEL_AUTO || p->kernel_variant > BDPT_KERNEL_BVH || p->kernel_variant == 2)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown kernel_variant");
     if (p->sample_order < BDPT_ORDER_AUTO || p->sample_order > BDPT_ORDER_ADAPTIVE)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_set_params: unknown sample_order");
@@ -651,6 +658,18 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_sph_surf, sph_s));
     HIP_TRY(ctx, dev_upload(ctx->d_pln_surf, pln_s));
     HIP_TRY(ctx, dev_upload(ctx->d_tri_surf, tri_s));
+    {
+        bdpt_bvh_host bvh;
+        ctx->have_bvh = bdpt_bvh_build(bound.data(), big_r2.data(), n_triangles, bvh);
+        if (!ctx->have_bvh) bvh = bdpt_bvh_host();
+        HIP_TRY(ctx, dev_upload(ctx->d_bvh_nodes, bvh.nodes));
+        HIP_TRY(ctx, dev_upload(ctx->d_bvh_leaf_sph, bvh.leaf_sph));
+        HIP_TRY(ctx, dev_upload(ctx->d_bvh_leaf_tri, bvh.leaf_tri));
+        HIP_TRY(ctx, dev_upload(ctx->d_bvh_brute, bvh.brute));
+        ctx->bvh_root = bvh.root;
+        ctx->bvh_n_brute = (int)bvh.brute.size();
+        ctx->bvh_depth = bvh.depth;
+    }
     /* AUTO's estimate, in instructions per ray: the LDS variant runs the full test (about 64) on every
      * triangle; the tiled variant runs the sphere test (13) on every triangle and the full test, with
      * scalar-load operands (about 110), on those some lane of a wavefront comes near -- practically
@@ -821,6 +840,8 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
     K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
+    K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_sph = ctx->d_bvh_leaf_sph; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
+    K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;
@@ -931,9 +952,12 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     if ((variant == BDPT_KERNEL_LDS || variant == BDPT_KERNEL_LDS2) &&
         bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) > BDPT_LDS_SCENE_MAX)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
-    /* AUTO: see the estimate in bdpt_upload_scene */
+    if (variant == BDPT_KERNEL_BVH && !ctx->have_bvh)
+        return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: the scene has no triangle hierarchy (too many triangles that no sphere bounds, or too deep for the walk's stack)");
+    /* AUTO: see the estimate in bdpt_upload_scene; scenes for the many-triangle kernels walk the hierarchy when they have one */
     if (variant == BDPT_KERNEL_AUTO)
-        variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && K.scene.n_triangles <= BDPT_CULL_MAX_TRIANGLES && !ctx->auto_tiled) ? BDPT_KERNEL_TILED
+        variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && K.scene.n_triangles <= BDPT_CULL_MAX_TRIANGLES && !ctx->auto_tiled)
+                      ? (ctx->have_bvh ? BDPT_KERNEL_BVH : BDPT_KERNEL_TILED)
                   : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
     /* Pixels sorted by the class of their next sample (bdpt_class_pool.h): launches in index order.  Left to itself the
      * library runs them so from BDPT_CPOOL_AUTO_MIN_SPP samples on (1080p Cornell box, sequential generator, running
@@ -1049,6 +1073,7 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
     else if (variant == BDPT_KERNEL_DIRECT) HIP_TRY(ctx, bdpt_launch_direct(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS) HIP_TRY(ctx, bdpt_launch_lds(K, aov, ctx->counters_on, ctx->stream));
     else if (variant == BDPT_KERNEL_LDS2) HIP_TRY(ctx, bdpt_launch_lds2(K, aov, ctx->counters_on, ctx->stream));
+    else if (variant == BDPT_KERNEL_BVH) HIP_TRY(ctx, bdpt_launch_bvh(K, aov, ctx->counters_on, ctx->stream));
     else HIP_TRY(ctx, bdpt_launch_tiled(K, aov, ctx->counters_on, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->have_launch = true;

@@ -1,0 +1,161 @@
+/*
+ * bdpt_bvh.h -- a bounding-volume hierarchy over the triangles' bounding spheres, for scenes of many triangles:
+ * the layout the device walks (bdpt_kernels.hip, closest_hit_bvh) and the host code that builds it at scene upload.
+ *
+ * The reference meets every ray with every triangle in index order and keeps a hit that is strictly nearer than the
+ * best so far (kernel0.cl:434-449): the winner is the hit with the least distance and, among equals, the least index.
+ * That is a property of the set of hits, not of the order they are found in, so a search may skip any triangle that
+ * cannot be hit and visit the others in any order, as long as it compares (distance, index) -- which is what the
+ * hierarchy is for.  Which triangles "cannot be hit" is decided by the same bounding spheres, with the same margins, as
+ * in the exhaustive many-triangle kernel (bdpt_kernels.hip, "Tiled variant"): a sphere's keep-region for a ray from o is
+ * the set of lines within
+ *     rho(o) = sqrt((1.05 R^2 + 1e-5 (|o|^2 + 1) + 2e-6 (|o|^2 + |c|^2)) / 0.99999)
+ * of its centre c.  With sqrt(a + b) <= sqrt(a) + sqrt(b):  rho(o) <= r_box + q(o),
+ *     r_box = 1.02471 R + 0.001416 |c|        stored: the half width of the triangle's box, rounded up
+ *     q(o)  = sqrt(1.2e-5 |o|^2 + 1e-5) * 1.00001   added per ray to every box
+ * so a line that the sphere test keeps passes through the box  c +- (r_box + q(o)),  and through every box that
+ * encloses it.  The walk tests the (widened) boxes of a node's two children with the slab method and a relative slack
+ * of 1e-5 on the comparison, a hundred times the rounding of the three operations per slab.
+ *
+ * Triangles whose sphere is unbounded (slivers, see bdpt_api.cpp) and the few that are far larger than the rest (the
+ * walls of a room around a soup of small triangles: their boxes would swallow every node above them) are kept out of
+ * the hierarchy in a short list that every ray tests in full.
+ *
+ * Built by median split of the longest axis of the centres' bounds, so the depth is ceil(log2(n / leaf size)) + 1
+ * whatever the scene looks like, and the per-lane stack of the walk (BDPT_BVH_STACK entries) is known to suffice.
+ */
+#ifndef BDPT_BVH_H
+#define BDPT_BVH_H
+
+#include "bdpt_layout.h"
+
+#define BDPT_BVH_NODE_F4 4        /* (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (child0, child1, -, -) */
+#define BDPT_BVH_LEAF_MAX 4       /* triangles per leaf */
+#define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack = deepest tree the device accepts */
+#define BDPT_BVH_BRUTE_MAX 1024   /* triangles outside the hierarchy, at most */
+#define BDPT_BVH_BIG_MAX 64       /* of which oversized ones */
+/* a child reference: >= 0 the index of an inner node; < 0 a leaf, ~ref = first entry | (entries - 1) << 28 */
+#define BDPT_BVH_NONE 0x7FFFFFFF  /* root of an empty hierarchy */
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct bdpt_bvh_host {
+    std::vector<float4> nodes;          /* BDPT_BVH_NODE_F4 per inner node */
+    std::vector<float4> leaf_sph;       /* (c.xyz, w) of the triangles in leaf order: what the exhaustive kernel's sphere test reads */
+    std::vector<uint32_t> leaf_tri;     /* their triangle indices */
+    std::vector<uint32_t> brute;        /* triangles outside the hierarchy, ascending */
+    int root = BDPT_BVH_NONE;
+    int depth = 0;                      /* inner levels above the deepest leaf */
+};
+
+/* bound[i] = (c.xyz, w), w = -inf for a sphere that culls nothing; big_r2[i] = 1.05 R^2 (infinite for the same ones).
+ * false: the scene cannot have a hierarchy (too many unbounded triangles, or too deep for the device's stack). */
+inline bool bdpt_bvh_build(const float4 *bound, const double *big_r2, int n, bdpt_bvh_host &out)
+{
+    out = bdpt_bvh_host();
+    struct Box { float lo[3], hi[3]; };
+    std::vector<Box> box((size_t)n);
+    std::vector<uint32_t> idx;
+    std::vector<double> radii;
+    idx.reserve(n);
+    auto unbounded = [&](int i) { return !(std::isfinite(big_r2[i])) || !(std::isfinite(bound[i].w)) || !std::isfinite(bound[i].x + bound[i].y + bound[i].z); };
+    for (int i = 0; i < n; i++)
+        if (!unbounded(i)) radii.push_back(std::sqrt(big_r2[i]));
+    double median = 0.0;
+    if (!radii.empty()) {
+        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+        median = radii[radii.size() / 2];
+    }
+    /* oversized: more than eight times the median radius; the BDPT_BVH_BIG_MAX largest of them leave the hierarchy */
+    std::vector<std::pair<double, uint32_t>> big;
+    for (int i = 0; i < n; i++)
+        if (!unbounded(i) && std::sqrt(big_r2[i]) > 8.0 * median) big.push_back({std::sqrt(big_r2[i]), (uint32_t)i});
+    std::sort(big.begin(), big.end(), [](const std::pair<double, uint32_t> &a, const std::pair<double, uint32_t> &b) { return a.first > b.first; });
+    if (big.size() > BDPT_BVH_BIG_MAX) big.resize(BDPT_BVH_BIG_MAX);
+    std::vector<char> out_of_tree((size_t)n, 0);
+    for (const auto &b : big) out_of_tree[b.second] = 1;
+    for (int i = 0; i < n; i++) {
+        if (unbounded(i)) out_of_tree[i] = 1;
+        if (out_of_tree[i]) { out.brute.push_back((uint32_t)i); continue; }
+        const double cx = bound[i].x, cy = bound[i].y, cz = bound[i].z;
+        const double r = std::sqrt(big_r2[i] / 0.99999) * (1.0 + 1e-6) + 0.001416 * std::sqrt(cx * cx + cy * cy + cz * cz) + 1e-30;
+        const double c[3] = {cx, cy, cz};
+        for (int k = 0; k < 3; k++) {
+            box[i].lo[k] = std::nextafter((float)(c[k] - r), -INFINITY);
+            box[i].hi[k] = std::nextafter((float)(c[k] + r), INFINITY);
+        }
+        idx.push_back((uint32_t)i);
+    }
+    if (out.brute.size() > BDPT_BVH_BRUTE_MAX) return false;
+    if (idx.empty()) return true;
+    out.leaf_sph.reserve(idx.size());
+    out.leaf_tri.reserve(idx.size());
+    out.nodes.reserve(idx.size() / 2 * BDPT_BVH_NODE_F4 + BDPT_BVH_NODE_F4);
+
+    struct Ref { int ref; Box b; int depth; };
+    /* recursion on [first, last) of idx; depth-first, so a subtree's nodes and leaves are contiguous */
+    struct Builder {
+        const float4 *bound;
+        std::vector<Box> &box;
+        std::vector<uint32_t> &idx;
+        bdpt_bvh_host &out;
+        Ref build(size_t first, size_t last)
+        {
+            Ref r;
+            for (int k = 0; k < 3; k++) { r.b.lo[k] = INFINITY; r.b.hi[k] = -INFINITY; }
+            const size_t count = last - first;
+            if (count <= BDPT_BVH_LEAF_MAX) {
+                std::sort(idx.begin() + first, idx.begin() + last);
+                const size_t at = out.leaf_tri.size();
+                for (size_t j = first; j < last; j++) {
+                    const uint32_t i = idx[j];
+                    out.leaf_tri.push_back(i);
+                    out.leaf_sph.push_back(bound[i]);
+                    for (int k = 0; k < 3; k++) { r.b.lo[k] = std::min(r.b.lo[k], box[i].lo[k]); r.b.hi[k] = std::max(r.b.hi[k], box[i].hi[k]); }
+                }
+                r.ref = ~(int)((uint32_t)at | (uint32_t)(count - 1) << 28);
+                r.depth = 0;
+                return r;
+            }
+            float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t j = first; j < last; j++) {
+                const float4 c = bound[idx[j]];
+                const float cc[3] = {c.x, c.y, c.z};
+                for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], cc[k]); chi[k] = std::max(chi[k], cc[k]); }
+            }
+            int axis = 0;
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            const size_t mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + last, [&](uint32_t a, uint32_t b) {
+                const float ca = axis == 0 ? bound[a].x : axis == 1 ? bound[a].y : bound[a].z;
+                const float cb = axis == 0 ? bound[b].x : axis == 1 ? bound[b].y : bound[b].z;
+                return ca < cb || (ca == cb && a < b);
+            });
+            const size_t node = out.nodes.size() / BDPT_BVH_NODE_F4;
+            out.nodes.resize(out.nodes.size() + BDPT_BVH_NODE_F4);
+            const Ref a = build(first, mid), b = build(mid, last);
+            float4 *q = &out.nodes[node * BDPT_BVH_NODE_F4];
+            q[0] = make_float4(a.b.lo[0], a.b.lo[1], a.b.lo[2], a.b.hi[0]);
+            q[1] = make_float4(a.b.hi[1], a.b.hi[2], b.b.lo[0], b.b.lo[1]);
+            q[2] = make_float4(b.b.lo[2], b.b.hi[0], b.b.hi[1], b.b.hi[2]);
+            float fa, fb;
+            static_assert(sizeof(float) == sizeof(int), "child references travel as the bits of a float");
+            std::memcpy(&fa, &a.ref, 4);
+            std::memcpy(&fb, &b.ref, 4);
+            q[3] = make_float4(fa, fb, 0.0f, 0.0f);
+            for (int k = 0; k < 3; k++) { r.b.lo[k] = std::min(a.b.lo[k], b.b.lo[k]); r.b.hi[k] = std::max(a.b.hi[k], b.b.hi[k]); }
+            r.ref = (int)node;
+            r.depth = 1 + std::max(a.depth, b.depth);
+            return r;
+        }
+    } builder{bound, box, idx, out};
+    if (idx.size() >= ((size_t)1 << 28)) return false;
+    const Ref root = builder.build(0, idx.size());
+    out.root = root.ref;
+    out.depth = root.depth;
+    return root.depth <= BDPT_BVH_STACK;
+}
+#endif

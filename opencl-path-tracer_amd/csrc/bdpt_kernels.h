@@ -19,6 +19,10 @@ hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_
  * per lane on what is left (the scene's cull records go to LDS as well). */
 hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 
+/* Scenes of many triangles: a hierarchy over the triangles' bounding spheres (bdpt_bvh.h, K.scene.bvh_*), walked by
+ * every lane for itself; same hits as the exhaustive searches. */
+hipError_t bdpt_launch_bvh(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
+
 /* The same work for scenes of any size: triangle records staged through wave-private LDS tiles. */
 hipError_t bdpt_launch_tiled(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream);
 

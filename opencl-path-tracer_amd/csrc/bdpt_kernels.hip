@@ -18,6 +18,7 @@
 #include "bdpt_device.h"
 #include "bdpt_slice.h"
 #include "bdpt_kernels.h"
+#include "bdpt_bvh.h"
 
 #include <algorithm>
 
@@ -480,7 +481,158 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
     return found;
 }
 
-enum { MODE_DIRECT = 0, MODE_LDS = 2, MODE_LDS2 = 3 };
+/* ------------------------------------------------------------------------- */
+/* Scenes of many triangles: the hierarchy of bdpt_bvh.h, walked by every lane for itself.
+ *
+ * Spheres and planes first, in the reference's order and with its strict comparison (they come before the triangles
+ * in kernel0.cl:388-449, so they win ties against triangles).  Then the triangles, in whatever order the walk finds
+ * them: a candidate replaces the best when its distance is less, or equal with a lower triangle index -- the outcome
+ * of the reference's in-order walk with its strict "<" (:441).  A candidate is a triangle whose leaf the ray's line
+ * reaches, that passes the exhaustive kernel's sphere test (same numbers, same margins: see "Tiled variant" below)
+ * and then the reference's own test, operation for operation.
+ *
+ * The walk: a node holds the boxes of its two children; a child is visited when the ray's line passes through its box
+ * widened by q(o) (bdpt_bvh.h), in front of the origin and not beyond the best hit so far; the nearer child first,
+ * the other one pushed on the lane's stack (one column of a [BDPT_BVH_STACK][64] array of LDS per wavefront, so the
+ * lanes' accesses never share a bank).  Rays whose direction is not of unit length (the sphere test does not
+ * apply, as in the exhaustive kernel) or whose numbers are not finite visit every node.                           */
+/* ------------------------------------------------------------------------- */
+
+/* best_consider for triangles met in any order: distance first (as the reference compares it: after the root), then index */
+BDPT_DEV void best_consider_unordered(Best &b, clm_f3 p, clm_f3 o, int i)
+{
+    const clm_f3 v = clm_sub3(p, o);
+    const float d2 = clm_dot3(v, v);
+    bool take = d2 < b.d2_lo;
+    const bool close_call = !take && d2 <= b.d2 * 1.000001f;   /* equal roots are at most two parts in 1e7 apart before the root */
+    if (__builtin_amdgcn_ballot_w64(close_call) != 0) {
+        asm volatile("");
+        if (close_call) {
+            const float s = clm_sqrt(d2), sb = clm_sqrt(b.d2);
+            take = s < sb || (s == sb && b.type == 2 && i < b.idx);
+        }
+    }
+    if (take) {
+        b.d2 = d2;
+        b.d2_lo = d2 > 1.0e-30f ? d2 * 0.999999f : 0.0f;
+        b.type = 2;
+        b.idx = i;
+        b.pos = p;
+    }
+}
+
+/* the reference's triangle test (kernel0.cl:273-312) on a record this lane loaded for itself; `i` goes through
+ * best_consider_unordered */
+BDPT_DEV void test_triangle_unordered(Best &b, const float4 *rec, int i, int skip, clm_f3 o, clm_f3 d)
+{
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    const float e2z = rec[5].x;
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float val = clm_dot3(d, n);                                                      /* :286 */
+    clm_f3 a = clm_make3(q0.w, q1.x, q1.y);
+    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
+    if (val > 0 || t < 0) return;                                                    /* :288, :292 */
+    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
+    clm_f3 e0 = clm_make3(q1.z, q1.w, q2.x);
+    clm_f3 c = clm_make3(q2.y, q2.z, q2.w);
+    clm_f3 e1 = clm_make3(q3.x, q3.y, q3.z);
+    clm_f3 bb = clm_make3(q3.w, q4.x, q4.y);
+    clm_f3 e2 = clm_make3(q4.z, q4.w, e2z);
+    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), e0), n);                          /* :298 */
+    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
+    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
+    if (dA < 0 || dB < 0 || dC < 0) return;                                          /* :304 */
+    if (i != skip) best_consider_unordered(b, p, o, i);                              /* :436, :441-448 */
+}
+
+template <bool COUNT = false>
+BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o, clm_f3 d, int otype, int oidx,
+                             unsigned long long *n_cull = nullptr, unsigned long long *n_exact = nullptr)
+{
+    Best b;
+    best_init(b);                                                         /* kernel0.cl:374, :384-385 */
+    const int skip_s = otype == 0 ? oidx : -1;                            /* :390 */
+    const int skip_p = otype == 1 ? oidx : -1;                            /* :415 */
+    const int skip_t = otype == 2 ? oidx : -1;                            /* :436 */
+    for (int i = 0; i < S.n_spheres; i++) {
+        const float4 s = uload(S.sph, i);
+        if (i != skip_s) test_sphere(b, s, i, o, d);
+    }
+    for (int i = 0; i < S.n_planes; i++) {
+        const float4 q0 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 0), q1 = uload(S.pln, (size_t)i * BDPT_PLN_F4 + 1);
+        if (i != skip_p) test_plane(b, q0, q1, i, o, d);
+    }
+    for (int k = 0; k < S.bvh_n_brute; k++) {                             /* the triangles outside the hierarchy */
+        const int i = (int)S.bvh_brute[k];
+        test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
+        if (COUNT) ++*n_exact;
+    }
+    if (S.bvh_root == BDPT_BVH_NONE) return finish_hit(S, b, d);
+
+    /* the sphere test's per-ray numbers, as in closest_hit_tiled */
+    const float dd = clm_dot3(d, d), oo = clm_dot3(o, o), od = clm_dot3(o, d);
+    const bool all = !(fabsf(dd - 1.0f) <= 4.0e-6f) || !(oo < 1.0e30f);    /* no cull for this ray (a NaN lands here too) */
+    const float bound = all ? INFINITY : 1.0e-5f * (oo + 1.0f) + 2.0e-6f * oo - 0.99999f * oo;
+    const clm_f3 o2 = clm_scale3(-2.0f * 0.99999f, o);
+    /* the boxes' widening for this ray, with room for the rounding of o +- q */
+    const float q = __builtin_sqrtf(1.2e-5f * oo + 1.0e-5f) * 1.001f + 2.0e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + 1.0f);
+    const clm_f3 op = clm_make3(o.x + q, o.y + q, o.z + q), om = clm_make3(o.x - q, o.y - q, o.z - q);
+    auto inverse = [](float x) { return 1.0f / (fabsf(x) < 1.0e-30f ? __builtin_copysignf(1.0e-30f, x) : x); };
+    const clm_f3 inv = clm_make3(inverse(d.x), inverse(d.y), inverse(d.z));
+    float reach = __builtin_sqrtf(b.d2) * 1.0001f;                        /* no hit beyond this parameter can win */
+    /* the ray's line against one box: does it pass, and where does it enter */
+    auto slab = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, float &enter) {
+        const float ax = (lox - op.x) * inv.x, bx = (hix - om.x) * inv.x;
+        const float ay = (loy - op.y) * inv.y, by = (hiy - om.y) * inv.y;
+        const float az = (loz - op.z) * inv.z, bz = (hiz - om.z) * inv.z;
+        const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+        const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+        const float slack = 1.0e-5f * (fabsf(t0) + fabsf(t1));
+        enter = t0;
+        return all || (!(t0 - slack > t1) && !(t1 < -slack) && !(t0 - slack > reach));
+    };
+    int cur = S.bvh_root, sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
+            const float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
+            float t0, t1;
+            const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t0);
+            const bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t1);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                const bool first0 = !(t1 < t0);
+                stack[sp * 64] = (uint32_t)(first0 ? c1 : c0);
+                sp++;
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
+        } else {
+            const uint32_t leaf = ~(uint32_t)cur;
+            const uint32_t first = leaf & 0x0FFFFFFFu, count = (leaf >> 28) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const float4 c = S.bvh_leaf_sph[first + k];
+                const float u = clm_fma(c.z, d.z, clm_fma(c.y, d.y, clm_fma(c.x, d.x, -od)));
+                const float t = clm_fma(c.z, o2.z, clm_fma(c.y, o2.y, clm_fma(c.x, o2.x, c.w)));
+                const float e = clm_fma(-u, u, t);
+                if (COUNT) ++*n_cull;
+                if (!(e > bound)) {
+                    const int i = (int)S.bvh_leaf_tri[first + k];
+                    test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
+                    if (COUNT) ++*n_exact;
+                }
+            }
+            reach = __builtin_sqrtf(b.d2) * 1.0001f;
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = (int)stack[sp * 64];
+    }
+    return finish_hit(S, b, d);
+}
+
+enum { MODE_DIRECT = 0, MODE_LDS = 2, MODE_LDS2 = 3, MODE_BVH = 4 };
 
 /* per-lane work counters of a counting launch */
 struct Tally {
@@ -529,6 +681,8 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
     if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact, T.clk);
 #endif
     if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact);
+    if (MODE == MODE_BVH)                                   /* the lane's column of its wavefront's stack, at the start of LDS */
+        return closest_hit_bvh<COUNT>(S, (uint32_t *)bdpt_lds + (threadIdx.x >> 6) * (BDPT_BVH_STACK * 64) + (threadIdx.x & 63), o, d, otype, oidx, &T.cull, &T.exact);
     return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
 }
 
@@ -567,7 +721,7 @@ BDPT_DEV bool sample_direct(const bdpt_kargs &K, float xt, float yt, uint32_t &w
         return true;
     }
 
-    const bool parked = MODE != MODE_DIRECT;
+    const bool parked = MODE == MODE_LDS || MODE == MODE_LDS2;
     volatile float4 *park = parked ? lane_park<MODE>(S) : nullptr;
     if (parked) {
         park_store(park + 0, eye.pos.x, eye.pos.y, eye.pos.z, __int_as_float(eye.type));
@@ -1343,6 +1497,12 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
         lds += park * (K.block / 64);
         if (MODE == bdpt::MODE_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return hipErrorInvalidValue;
     }
+    if (MODE == bdpt::MODE_BVH) {
+        /* a hierarchy has leaves; one with inner nodes has those too */
+        if (K.scene.bvh_root != BDPT_BVH_NONE && (!K.scene.bvh_leaf_sph || !K.scene.bvh_leaf_tri || (K.scene.bvh_root >= 0 && !K.scene.bvh_nodes))) return hipErrorInvalidValue;
+        if (K.scene.bvh_n_brute > 0 && !K.scene.bvh_brute) return hipErrorInvalidValue;
+        lds = (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t);                 /* one wavefront per workgroup, its lanes' stacks */
+    }
     dim3 grid;
     const dim3 block(K.block);
     const hipError_t e = sliced_grid(K, grid, stream);
@@ -1385,6 +1545,11 @@ hipError_t bdpt_launch_lds(const bdpt_kargs &K, bool aov, bool count, hipStream_
 hipError_t bdpt_launch_lds2(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
 {
     return launch_per_pixel<bdpt::MODE_LDS2>(K, aov, count, stream);
+}
+
+hipError_t bdpt_launch_bvh(const bdpt_kargs &K, bool aov, bool count, hipStream_t stream)
+{
+    return launch_per_pixel<bdpt::MODE_BVH>(K, aov, count, stream);
 }
 
 /* Paths sorted by phase (bdpt_pool.h).  Wavefronts per workgroup: as many as keep the most wavefronts on a compute unit

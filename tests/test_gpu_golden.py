@@ -46,8 +46,8 @@ def test_closest_hit_matches_golden(bdpt):
 
 
 def _region_variants(case):
-    # the 100 000-triangle scene does not fit the LDS-resident kernel; AUTO must resolve to TILED there
-    return [0, 1, 4] if "soup100k" in case else [0, 1, 3, 4, 5]
+    # the 100 000-triangle scene does not fit the LDS-resident kernels; AUTO must resolve to the hierarchy there
+    return [0, 1, 4, 6] if "soup100k" in case else [0, 1, 3, 4, 5, 6]
 
 
 @pytest.mark.parametrize("case,variant", [(c, v) for c in gu.REGION_CASES for v in _region_variants(c)])
@@ -75,7 +75,7 @@ def test_region_of_the_1080p_frame_matches_golden(bdpt, case, variant):
             assert np.array_equal(crop(ctx.read_aov(bdpt.AOV_RADIANCE)).view(np.uint32), g["out_radiance"][s].view(np.uint32))
             assert np.array_equal(crop(ctx.read_accum()).view(np.uint32), g["out_accum"][s].view(np.uint32))
         if "soup100k" in case:
-            assert ctx.last_launch_variant() == (bdpt.KERNEL_DIRECT if variant == 1 else bdpt.KERNEL_TILED)
+            assert ctx.last_launch_variant() == {0: bdpt.KERNEL_BVH, 1: bdpt.KERNEL_DIRECT, 4: bdpt.KERNEL_TILED, 6: bdpt.KERNEL_BVH}[variant]
         seeds_after = ctx.read_seeds()
         xs, ys = np.meshgrid(np.arange(x0, x0 + w), np.arange(y0, y0 + h))
         assert np.array_equal(seeds_after[(xs * H + ys) * 4 + 3], g["seed_words_after"])

@@ -138,7 +138,7 @@ def test_near_ties_resolve_like_the_reference_order(bdpt, oracle):
     ctx.close()
 
 
-VARIANTS = [1, 3, 4, 5]   # DIRECT, LDS, TILED, LDS2: every kernel variant must give the same bits
+VARIANTS = [1, 3, 4, 5, 6]   # DIRECT, LDS, TILED, LDS2, BVH: every kernel variant must give the same bits
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -182,9 +182,10 @@ def test_other_scenes_parity(bdpt, oracle, scene_name, W, H, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1, 4, 6])
 def test_soup_scene_parity(bdpt, oracle, variant):
-    """Cornell + 3000 soup triangles, 32x32 x 2 spp (the exhaustive search over many primitives; AUTO must pick TILED)."""
+    """Cornell + 3000 soup triangles, 32x32 x 2 spp (the searches over many primitives: plain, exhaustive with bounding
+    spheres, hierarchy; AUTO must pick the hierarchy)."""
     scene = bdpt.Scene.soup(3000)
     ctx, st, p = _pair(bdpt, oracle, scene, 32, 32, seed=5, kernel_variant=variant)
     ctx.render(2)
@@ -193,17 +194,17 @@ def test_soup_scene_parity(bdpt, oracle, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 4])
 def test_full_size_soup_region_against_the_oracle(bdpt, oracle, variant):
-    """Cornell box + 100 000 soup triangles on the 1920x1080 frame, a 32x32 region x 2 spp, in one launch: the tiled
-    kernel over all 521 tiles (AUTO must pick it) and the plain walk, against the oracle run on the same region."""
+    """Cornell box + 100 000 soup triangles on the 1920x1080 frame, a 32x32 region x 2 spp, in one launch: the hierarchy
+    (AUTO must pick it), the tiled kernel over all 521 tiles and the plain walk, against the oracle run on the same region."""
     scene = bdpt.Scene.soup(100000)
     W, H = 1920, 1080
     region = (1100, 380, 32, 32)
     ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=0xC4, kernel_variant=variant)
     ctx.set_region(*region)
     ctx.render(2)
-    assert ctx.last_launch_variant() == (bdpt.KERNEL_TILED if variant == 0 else bdpt.KERNEL_DIRECT)
+    assert ctx.last_launch_variant() == {0: bdpt.KERNEL_BVH, 1: bdpt.KERNEL_DIRECT, 4: bdpt.KERNEL_TILED}[variant]
     oracle.render(st, scene, scene.camera, p, 2, region=region, n_threads=16)
     _compare(bdpt, ctx, st, "100k soup region:")
     assert (st.eye_hit[380:412, 1100:1132, 1] >= 12).any()
@@ -295,7 +296,7 @@ def test_sample_orders_take_the_same_samples(bdpt, oracle, variant, p_continue, 
     np.testing.assert_allclose(a[0], b[0], rtol=2e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
 @pytest.mark.parametrize("sampler", [1, 2, 3])
 def test_alternative_samplers_match_the_oracle(bdpt, oracle, variant, sampler):
     """HEMISPHERE, REFLECTIVE and LAMBERT_IMP bounce samplers: per-sample parity in STREAM mode and a class-ordered STRIDED + SUM
@@ -340,7 +341,7 @@ def test_path_trace_integrator_matches_the_oracle(bdpt, oracle, scene_name):
 
 def test_unknown_variants_and_samplers_are_refused(bdpt):
     ctx = bdpt.Context(16, 16)
-    for bad in (2, 6, -1):                      # 2 was a variant that no longer exists
+    for bad in (2, 7, -1):                      # 2 was a variant that no longer exists
         with pytest.raises(bdpt.BdptError, match="kernel_variant"):
             ctx.set_params(bdpt.default_params(kernel_variant=bad))
     with pytest.raises(bdpt.BdptError, match="sampler"):
@@ -370,12 +371,14 @@ def _mixed_soup(bdpt, n, seed):
 
 
 @pytest.mark.parametrize("seed,n", [(1, 700), (2, 1500), (3, 260)])
-def test_tiled_kernel_bounding_sphere_cull_never_drops_a_hit(bdpt, oracle, seed, n):
-    """The tiled kernel skips a triangle for a ray that clearly passes its bounding sphere.  Triangles from 1e-3 to 4
-    units, slivers and far-away ones, seen by eye, connection and bounce rays: every id, count and bit as the oracle."""
+@pytest.mark.parametrize("variant", [4, 6])
+def test_tiled_kernel_bounding_sphere_cull_never_drops_a_hit(bdpt, oracle, seed, n, variant):
+    """The tiled kernel skips a triangle for a ray that clearly passes its bounding sphere, and the hierarchy skips whole
+    boxes of them.  Triangles from 1e-3 to 4 units, slivers and far-away ones, seen by eye, connection and bounce rays:
+    every id, count and bit as the oracle."""
     scene = _mixed_soup(bdpt, n, seed)
     W, H = 56, 40
-    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=bdpt.KERNEL_TILED)
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=seed, kernel_variant=variant)
     for s in range(3):
         ctx.render(2)
         oracle.render(st, scene, scene.camera, p, 2, n_threads=8)
@@ -548,8 +551,8 @@ def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
     assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS     # no triangles: nothing for two stages to do
     assert variant_for(bdpt.Scene.outdoor()) == bdpt.KERNEL_LDS
     assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS2
-    assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_TILED
-    assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_TILED
+    assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_BVH
+    assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_BVH
 
 
 def test_class_ordered_launches_over_random_parameters(bdpt, oracle):
@@ -664,7 +667,7 @@ def test_tiled_cull_with_plane_normals_that_are_not_unit_length(bdpt, oracle, sc
     tri["surface"] = rng.choice([0, 1, 3, 4], n)
     sc.triangles = np.concatenate([sc.triangles, tri])
     W, H = 56, 40
-    for variant in (bdpt.KERNEL_TILED, bdpt.KERNEL_DIRECT):
+    for variant in (bdpt.KERNEL_TILED, bdpt.KERNEL_BVH, bdpt.KERNEL_DIRECT):
         ctx, st, p = _pair(bdpt, oracle, sc, W, H, seed=8, kernel_variant=variant)
         ctx.render(6)
         oracle.render(st, sc, sc.camera, p, 6, n_threads=8)

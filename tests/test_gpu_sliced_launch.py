@@ -63,7 +63,7 @@ def test_mode_constants(bdpt):
     assert (bdpt.RNG_STRIDED, bdpt.ACCUM_SUM, bdpt.ORDER_INDEX, bdpt.ORDER_ROULETTE_CLASS, bdpt.ORDER_ADAPTIVE) == (1, 1, 1, 2, 3)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
 @pytest.mark.parametrize("mode", sorted(MODES))
 def test_sliced_launch_is_bit_identical(bdpt, variant, mode):
     scene = bdpt.Scene.soup(60) if variant == 4 else bdpt.Scene.cornell()

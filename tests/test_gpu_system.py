@@ -113,7 +113,7 @@ def test_full_frame_properties_at_benchmark_size(bdpt):
         c = ctx.read_accum()
     np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
     # every kernel variant gives the same frame
-    for variant in (bdpt.KERNEL_DIRECT, bdpt.KERNEL_TILED, bdpt.KERNEL_LDS):
+    for variant in (bdpt.KERNEL_DIRECT, bdpt.KERNEL_TILED, bdpt.KERNEL_LDS, bdpt.KERNEL_BVH):
         v, _ = _render(bdpt, scene, W, H, 8, 1, kernel_variant=variant, **kw)
         assert np.array_equal(a.view(np.uint32), v.view(np.uint32))
     img = a / 8

@@ -41,8 +41,9 @@ sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
 F_SPHERE, F_PLANE, F_TRIANGLE, F_RAY_FIXED = 35, 37, 113, 30   # algorithmic flops per primitive test / per ray
 F_PATH_FULL, F_PATH_EARLY = 500, 100                           # per path outside the closest-hit queries
-F_CULL = {4: 15, 5: 29}         # flops of the cheap test in front of the triangle test: bounding sphere (TILED: 7 fma + compare);
-                                # conservative plane test (LDS2), for two triangles that share only the plane; see f_cull_lds2
+F_CULL = {4: 15, 5: 29, 6: 14}  # flops of the cheap test in front of the triangle test: bounding sphere (TILED: 7 fma + compare);
+                                # conservative plane test (LDS2), for two triangles that share only the plane; see f_cull_lds2;
+                                # one box of the hierarchy (BVH: 6 subtractions, 6 products, 2 scalings; the counter counts boxes)
 
 
 def recorded(name, key):
@@ -302,7 +303,7 @@ def main():
         per_rank_ms = gathered
 
     variant = ctx.last_launch_variant()
-    variant_name = {1: "DIRECT", 3: "LDS", 4: "TILED", 5: "LDS2"}.get(variant, str(variant))
+    variant_name = {1: "DIRECT", 3: "LDS", 4: "TILED", 5: "LDS2", 6: "BVH"}.get(variant, str(variant))
     weak_chunks = ctx.last_launch_chunks()
 
     # Strong scaling (N > 1): the SAME total work as one GPU's step -- `strong_spp` samples per pixel in all -- dealt to the
@@ -441,7 +442,7 @@ def main():
             "rays_traced": rays, "rays_reference_formulation": rays_ref, "paths_full": full, "paths_early": early,
             "flops_per_ray": f_ray, "cull_tests": n_cull, "exact_triangle_tests_after_cull": n_exact,
             "note": ("frac prices the tests the timed launch ran (rays traced x per-primitive flops of the reference's tests; for "
-                     "kernels with a cheap conservative test in front of the triangle test: cull tests x %s + triangle tests "
+                     "kernels with a cheap conservative test (bounding sphere, plane, box of a hierarchy) in front of the triangle test: cull tests x %s + triangle tests "
                      "actually run x 113); frac_reference_formulation prices every ray and every (ray, primitive) pair of "
                      "the reference's formulation, which a kernel that culls does not execute -- it may exceed 1" % ("n/a" if f_cull is None else "%.1f" % f_cull)),
         }

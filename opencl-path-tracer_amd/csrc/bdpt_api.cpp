@@ -63,7 +63,7 @@ struct bdpt_ctx {
     uint32_t cull_group[BDPT_CULL_MAX_TRIANGLES / 32] = {};
     uint32_t *d_sph_surf = nullptr, *d_pln_surf = nullptr, *d_tri_surf = nullptr;
     /* hierarchy over the triangles' bounding spheres (bdpt_bvh.h), built by every scene upload that has triangles */
-    float4 *d_bvh_nodes = nullptr, *d_bvh_leaf_sph = nullptr;
+    float4 *d_bvh_nodes = nullptr;
     uint32_t *d_bvh_leaf_tri = nullptr, *d_bvh_brute = nullptr;
     int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0;
     bool have_bvh = false;              /* false: the scene cannot have one (bdpt_bvh_build), BDPT_KERNEL_BVH is refused */
@@ -288,7 +288,7 @@ void bdpt_destroy(bdpt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->d_sph); dev_free(ctx->d_pln); dev_free(ctx->d_tri); dev_free(ctx->d_tri_bound); dev_free(ctx->d_tri_cull); dev_free(ctx->d_surf);
     dev_free(ctx->d_sph_surf); dev_free(ctx->d_pln_surf); dev_free(ctx->d_tri_surf);
-    dev_free(ctx->d_bvh_nodes); dev_free(ctx->d_bvh_leaf_sph); dev_free(ctx->d_bvh_leaf_tri); dev_free(ctx->d_bvh_brute);
+    dev_free(ctx->d_bvh_nodes); dev_free(ctx->d_bvh_leaf_tri); dev_free(ctx->d_bvh_brute);
     dev_free(ctx->d_seed_w); dev_free(ctx->d_accum_own);
     dev_free(ctx->d_aov_eye); dev_free(ctx->d_aov_hash); dev_free(ctx->d_aov_draws); dev_free(ctx->d_aov_rays);
     dev_free(ctx->d_aov_rad); dev_free(ctx->d_counters); dev_free(ctx->d_slice_sync); dev_free(ctx->d_slice_cursor);
@@ -425,6 +425,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     std::vector<float4> cull_third(n_triangles);       /* third coordinate plane and longest edge of each triangle */
     std::vector<double> cull_len(n_triangles);
     std::vector<double> big_r2(n_triangles);           /* 1.05 R^2 of each bounding sphere, for AUTO's estimate */
+    std::vector<double> normal_off(n_triangles);       /* |stored unit normal - true unit normal| of each triangle */
     double cull_c = 0.0;
     for (int i = 0; i < n_spheres; i++) {
         const bdpt_sphere &s = spheres[i];
@@ -490,6 +491,7 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
             const double area2 = std::sqrt(crx * crx + cry * cry + crz * crz);
             const double nt[3] = {crx / area2, cry / area2, crz / area2};
             const double theta = std::sqrt((n.x - nt[0]) * (n.x - nt[0]) + (n.y - nt[1]) * (n.y - nt[1]) + (n.z - nt[2]) * (n.z - nt[2]));
+            normal_off[i] = theta;
             const double longest = std::sqrt(longest2);
             const double scale = (area2 / longest) / (104.0 * 0x1p-24);                    /* s */
             auto edge_plane = [&](const double *from, const double *to, const double *vertex, float4 &out) {
@@ -660,10 +662,10 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
     HIP_TRY(ctx, dev_upload(ctx->d_tri_surf, tri_s));
     {
         bdpt_bvh_host bvh;
-        ctx->have_bvh = bdpt_bvh_build(bound.data(), big_r2.data(), n_triangles, bvh);
+        auto vertex = [&](int i, int k) { return k == 0 ? triangles[i].p0 : k == 1 ? triangles[i].p1 : triangles[i].p2; };
+        ctx->have_bvh = bdpt_bvh_build(vertex, bound.data(), big_r2.data(), normal_off.data(), n_triangles, bvh);
         if (!ctx->have_bvh) bvh = bdpt_bvh_host();
         HIP_TRY(ctx, dev_upload(ctx->d_bvh_nodes, bvh.nodes));
-        HIP_TRY(ctx, dev_upload(ctx->d_bvh_leaf_sph, bvh.leaf_sph));
         HIP_TRY(ctx, dev_upload(ctx->d_bvh_leaf_tri, bvh.leaf_tri));
         HIP_TRY(ctx, dev_upload(ctx->d_bvh_brute, bvh.brute));
         ctx->bvh_root = bvh.root;
@@ -840,7 +842,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.scene.sph = ctx->d_sph; K.scene.sph_surf = ctx->d_sph_surf;
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
     K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
-    K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_sph = ctx->d_bvh_leaf_sph; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
+    K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
     K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();

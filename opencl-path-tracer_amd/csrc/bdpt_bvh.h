@@ -1,25 +1,31 @@
 /*
- * bdpt_bvh.h -- a bounding-volume hierarchy over the triangles' bounding spheres, for scenes of many triangles:
- * the layout the device walks (bdpt_kernels.hip, closest_hit_bvh) and the host code that builds it at scene upload.
+ * bdpt_bvh.h -- a bounding-volume hierarchy over the triangles, for scenes of many of them: the layout the device
+ * walks (bdpt_kernels.hip, closest_hit_bvh) and the host code that builds it at scene upload.
  *
  * The reference meets every ray with every triangle in index order and keeps a hit that is strictly nearer than the
  * best so far (kernel0.cl:434-449): the winner is the hit with the least distance and, among equals, the least index.
  * That is a property of the set of hits, not of the order they are found in, so a search may skip any triangle that
  * cannot be hit and visit the others in any order, as long as it compares (distance, index) -- which is what the
- * hierarchy is for.  Which triangles "cannot be hit" is decided by the same bounding spheres, with the same margins, as
- * in the exhaustive many-triangle kernel (bdpt_kernels.hip, "Tiled variant"): a sphere's keep-region for a ray from o is
- * the set of lines within
- *     rho(o) = sqrt((1.05 R^2 + 1e-5 (|o|^2 + 1) + 2e-6 (|o|^2 + |c|^2)) / 0.99999)
- * of its centre c.  With sqrt(a + b) <= sqrt(a) + sqrt(b):  rho(o) <= r_box + q(o),
- *     r_box = 1.02471 R + 0.001416 |c|        stored: the half width of the triangle's box, rounded up
- *     q(o)  = sqrt(1.2e-5 |o|^2 + 1e-5) * 1.00001   added per ray to every box
- * so a line that the sphere test keeps passes through the box  c +- (r_box + q(o)),  and through every box that
- * encloses it.  The walk tests the (widened) boxes of a node's two children with the slab method and a relative slack
- * of 1e-5 on the comparison, a hundred times the rounding of the three operations per slab.
+ * hierarchy is for.
  *
- * Triangles whose sphere is unbounded (slivers, see bdpt_api.cpp) and the few that are far larger than the rest (the
- * walls of a room around a soup of small triangles: their boxes would swallow every node above them) are kept out of
- * the hierarchy in a short list that every ray tests in full.
+ * Which triangles cannot be hit.  The reference's test (kernel0.cl:273-312) accepts a point p = o + t d, computed in
+ * float, that passes three edge tests, computed in float: p lies on the ray's line up to the rounding of o + t d,
+ * 1.2e-7 (|o| + |p|); it lies in the triangle's plane up to t times the rounding of d.n and the rounding of (a - o).n,
+ * some 1e-6 (|o| + |p|), plus theta R for a stored unit normal that is off by the angle theta from the true one (it
+ * comes from a cross product of rounded edges; measured per triangle at upload; R the largest distance of a vertex
+ * from the centroid); and it lies inside the prism over the triangle along that normal up to the rounding of the edge
+ * expressions, some 1e-6 (|p| + R).  A box around the vertices widened by
+ *     m   = (0.01 + 10 theta) R + 2e-5 (1 + |c|_1)    per triangle, stored (c the centroid, |.|_1 the sum of absolute coordinates)
+ *     q(o) = 2e-5 (1 + |o|_1)                per ray, added to every box by the walk
+ * -- ten times the normal's share, some twenty times the rounding's -- therefore contains every point the test can
+ * accept, and so does every box that encloses it.  The walk tests the (widened) boxes of a node's two children with
+ * the slab method and a relative slack of 1e-5 on the comparisons, a hundred times the rounding of the three
+ * operations per slab.
+ *
+ * Triangles that are not well shaped or whose normal is off by 1e-3 or more (slivers, specks far from the origin:
+ * what their edge tests accept need not resemble the triangle) and the
+ * few that are far larger than the rest (the walls of a room around a soup of small triangles: their boxes would
+ * swallow every node above them) are kept out of the hierarchy in a short list that every ray tests in full.
  *
  * Built by median split of the longest axis of the centres' bounds, so the depth is ceil(log2(n / leaf size)) + 1
  * whatever the scene looks like, and the per-lane stack of the walk (BDPT_BVH_STACK entries) is known to suffice.
@@ -30,8 +36,12 @@
 #include "bdpt_layout.h"
 
 #define BDPT_BVH_NODE_F4 4        /* (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (child0, child1, -, -) */
-#define BDPT_BVH_LEAF_MAX 4       /* triangles per leaf */
+#ifndef BDPT_BVH_LEAF_MAX
+#define BDPT_BVH_LEAF_MAX 2       /* triangles per leaf */
+#endif
+#ifndef BDPT_BVH_STACK
 #define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack = deepest tree the device accepts */
+#endif
 #define BDPT_BVH_BRUTE_MAX 1024   /* triangles outside the hierarchy, at most */
 #define BDPT_BVH_BIG_MAX 64       /* of which oversized ones */
 /* a child reference: >= 0 the index of an inner node; < 0 a leaf, ~ref = first entry | (entries - 1) << 28 */
@@ -44,16 +54,17 @@
 
 struct bdpt_bvh_host {
     std::vector<float4> nodes;          /* BDPT_BVH_NODE_F4 per inner node */
-    std::vector<float4> leaf_sph;       /* (c.xyz, w) of the triangles in leaf order: what the exhaustive kernel's sphere test reads */
-    std::vector<uint32_t> leaf_tri;     /* their triangle indices */
+    std::vector<uint32_t> leaf_tri;     /* triangle indices in leaf order */
     std::vector<uint32_t> brute;        /* triangles outside the hierarchy, ascending */
     int root = BDPT_BVH_NONE;
     int depth = 0;                      /* inner levels above the deepest leaf */
 };
 
-/* bound[i] = (c.xyz, w), w = -inf for a sphere that culls nothing; big_r2[i] = 1.05 R^2 (infinite for the same ones).
+/* vertex(i, k) = const float * to the three coordinates of vertex k of triangle i; bound[i] = (centroid, w), w = -inf
+ * for a triangle that is not well shaped; big_r2[i] = 1.05 R^2 (infinite for the same ones); theta[i] = |stored normal - true normal|.
  * false: the scene cannot have a hierarchy (too many unbounded triangles, or too deep for the device's stack). */
-inline bool bdpt_bvh_build(const float4 *bound, const double *big_r2, int n, bdpt_bvh_host &out)
+template <class Vertex>
+inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big_r2, const double *theta, int n, bdpt_bvh_host &out)
 {
     out = bdpt_bvh_host();
     struct Box { float lo[3], hi[3]; };
@@ -61,7 +72,7 @@ inline bool bdpt_bvh_build(const float4 *bound, const double *big_r2, int n, bdp
     std::vector<uint32_t> idx;
     std::vector<double> radii;
     idx.reserve(n);
-    auto unbounded = [&](int i) { return !(std::isfinite(big_r2[i])) || !(std::isfinite(bound[i].w)) || !std::isfinite(bound[i].x + bound[i].y + bound[i].z); };
+    auto unbounded = [&](int i) { return !(theta[i] < 1.0e-3) || !(std::isfinite(big_r2[i])) || !(std::isfinite(bound[i].w)) || !std::isfinite(bound[i].x + bound[i].y + bound[i].z); };
     for (int i = 0; i < n; i++)
         if (!unbounded(i)) radii.push_back(std::sqrt(big_r2[i]));
     double median = 0.0;
@@ -80,18 +91,16 @@ inline bool bdpt_bvh_build(const float4 *bound, const double *big_r2, int n, bdp
     for (int i = 0; i < n; i++) {
         if (unbounded(i)) out_of_tree[i] = 1;
         if (out_of_tree[i]) { out.brute.push_back((uint32_t)i); continue; }
-        const double cx = bound[i].x, cy = bound[i].y, cz = bound[i].z;
-        const double r = std::sqrt(big_r2[i] / 0.99999) * (1.0 + 1e-6) + 0.001416 * std::sqrt(cx * cx + cy * cy + cz * cz) + 1e-30;
-        const double c[3] = {cx, cy, cz};
+        const double m = (0.01 + 10.0 * theta[i]) * std::sqrt(big_r2[i] / 1.05) + 2.0e-5 * (1.0 + std::fabs((double)bound[i].x) + std::fabs((double)bound[i].y) + std::fabs((double)bound[i].z));
         for (int k = 0; k < 3; k++) {
-            box[i].lo[k] = std::nextafter((float)(c[k] - r), -INFINITY);
-            box[i].hi[k] = std::nextafter((float)(c[k] + r), INFINITY);
+            const double v[3] = {vertex(i, 0)[k], vertex(i, 1)[k], vertex(i, 2)[k]};
+            box[i].lo[k] = std::nextafter((float)(std::min(v[0], std::min(v[1], v[2])) - m), -INFINITY);
+            box[i].hi[k] = std::nextafter((float)(std::max(v[0], std::max(v[1], v[2])) + m), INFINITY);
         }
         idx.push_back((uint32_t)i);
     }
     if (out.brute.size() > BDPT_BVH_BRUTE_MAX) return false;
     if (idx.empty()) return true;
-    out.leaf_sph.reserve(idx.size());
     out.leaf_tri.reserve(idx.size());
     out.nodes.reserve(idx.size() / 2 * BDPT_BVH_NODE_F4 + BDPT_BVH_NODE_F4);
 
@@ -113,7 +122,6 @@ inline bool bdpt_bvh_build(const float4 *bound, const double *big_r2, int n, bdp
                 for (size_t j = first; j < last; j++) {
                     const uint32_t i = idx[j];
                     out.leaf_tri.push_back(i);
-                    out.leaf_sph.push_back(bound[i]);
                     for (int k = 0; k < 3; k++) { r.b.lo[k] = std::min(r.b.lo[k], box[i].lo[k]); r.b.hi[k] = std::max(r.b.hi[k], box[i].hi[k]); }
                 }
                 r.ref = ~(int)((uint32_t)at | (uint32_t)(count - 1) << 28);

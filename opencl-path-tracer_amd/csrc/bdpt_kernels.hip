@@ -487,15 +487,13 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
  * Spheres and planes first, in the reference's order and with its strict comparison (they come before the triangles
  * in kernel0.cl:388-449, so they win ties against triangles).  Then the triangles, in whatever order the walk finds
  * them: a candidate replaces the best when its distance is less, or equal with a lower triangle index -- the outcome
- * of the reference's in-order walk with its strict "<" (:441).  A candidate is a triangle whose leaf the ray's line
- * reaches, that passes the exhaustive kernel's sphere test (same numbers, same margins: see "Tiled variant" below)
- * and then the reference's own test, operation for operation.
+ * of the reference's in-order walk with its strict "<" (:441).  A candidate is a triangle whose leaf the ray reaches;
+ * it goes through the reference's own test, operation for operation.
  *
- * The walk: a node holds the boxes of its two children; a child is visited when the ray's line passes through its box
+ * The walk: a node holds the boxes of its two children; a child is visited when the ray passes through its box
  * widened by q(o) (bdpt_bvh.h), in front of the origin and not beyond the best hit so far; the nearer child first,
  * the other one pushed on the lane's stack (one column of a [BDPT_BVH_STACK][64] array of LDS per wavefront, so the
- * lanes' accesses never share a bank).  Rays whose direction is not of unit length (the sphere test does not
- * apply, as in the exhaustive kernel) or whose numbers are not finite visit every node.                           */
+ * lanes' accesses never share a bank).  A ray whose numbers are not finite visits every node.                     */
 /* ------------------------------------------------------------------------- */
 
 /* best_consider for triangles met in any order: distance first (as the reference compares it: after the root), then index */
@@ -545,6 +543,15 @@ BDPT_DEV void test_triangle_unordered(Best &b, const float4 *rec, int i, int ski
     if (i != skip) best_consider_unordered(b, p, o, i);                              /* :436, :441-448 */
 }
 
+/* -DBDPT_BVH_STATS (tools/bvh_stats.py): how well the lanes of a wavefront keep together in the walk.  Sums over all
+ * searches of a launch: node steps of the lanes / trips of the wavefronts through the node loop / leaves of the lanes /
+ * trips through the leaf block / searches of the lanes / searches of the wavefronts. */
+#ifdef BDPT_BVH_STATS
+__device__ unsigned long long bvh_stats[8];
+#define BDPT_BVH_STAT(k, n) atomicAdd(&bvh_stats[k], (unsigned long long)(n))
+#define BDPT_BVH_FIRST_LANE (__builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_ballot_w64(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_ballot_w64(true), 0u)) == 0)
+#endif
+
 template <bool COUNT = false>
 BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o, clm_f3 d, int otype, int oidx,
                              unsigned long long *n_cull = nullptr, unsigned long long *n_exact = nullptr)
@@ -569,17 +576,15 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
     }
     if (S.bvh_root == BDPT_BVH_NONE) return finish_hit(S, b, d);
 
-    /* the sphere test's per-ray numbers, as in closest_hit_tiled */
-    const float dd = clm_dot3(d, d), oo = clm_dot3(o, o), od = clm_dot3(o, d);
-    const bool all = !(fabsf(dd - 1.0f) <= 4.0e-6f) || !(oo < 1.0e30f);    /* no cull for this ray (a NaN lands here too) */
-    const float bound = all ? INFINITY : 1.0e-5f * (oo + 1.0f) + 2.0e-6f * oo - 0.99999f * oo;
-    const clm_f3 o2 = clm_scale3(-2.0f * 0.99999f, o);
-    /* the boxes' widening for this ray, with room for the rounding of o +- q */
-    const float q = __builtin_sqrtf(1.2e-5f * oo + 1.0e-5f) * 1.001f + 2.0e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + 1.0f);
+    const float dd = clm_dot3(d, d), oo = clm_dot3(o, o);
+    const bool all = !(oo < 1.0e30f) || !(dd > 1.0e-30f && dd < 1.0e30f);  /* no box test for this ray (a NaN lands here too) */
+    /* the boxes' widening for this ray */
+    const float q = 2.0e-5f * (1.0f + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
     const clm_f3 op = clm_make3(o.x + q, o.y + q, o.z + q), om = clm_make3(o.x - q, o.y - q, o.z - q);
     auto inverse = [](float x) { return 1.0f / (fabsf(x) < 1.0e-30f ? __builtin_copysignf(1.0e-30f, x) : x); };
     const clm_f3 inv = clm_make3(inverse(d.x), inverse(d.y), inverse(d.z));
-    float reach = __builtin_sqrtf(b.d2) * 1.0001f;                        /* no hit beyond this parameter can win */
+    const float per_length = 1.0001f / __builtin_sqrtf(dd);               /* ray parameter per unit of distance, rounded up */
+    float reach = __builtin_sqrtf(b.d2) * per_length;                     /* no hit beyond this parameter can win */
     /* the ray's line against one box: does it pass, and where does it enter */
     auto slab = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, float &enter) {
         const float ax = (lox - op.x) * inv.x, bx = (hix - om.x) * inv.x;
@@ -587,16 +592,32 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
         const float az = (loz - op.z) * inv.z, bz = (hiz - om.z) * inv.z;
         const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
         const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-        const float slack = 1.0e-5f * (fabsf(t0) + fabsf(t1));
         enter = t0;
-        return all || (!(t0 - slack > t1) && !(t1 < -slack) && !(t0 - slack > reach));
+        /* entry no later than exit, exit not behind the origin, entry not beyond the best hit: with the entry rounded
+         * down and the exit up by 1e-5 of themselves.  (The box reaches q(o) beyond any point the triangle test can
+         * accept, so an exit parameter that should be positive is not zero or less by rounding.) */
+        const float in = __builtin_fmaxf(t0 * 0.99999f, 0.0f), out = __builtin_fminf(t1 * 1.00001f, reach);
+        return all || !(in > out);
     };
+    /* Two loops in turn, so that the lanes of a wavefront run the same code most of the time: every lane walks down
+     * to its next leaf (or to the end of its walk) and waits there; then all lanes that have one run the reference's
+     * test on their leaf's triangles together.  (Letting a lane collect two, four or eight leaves before the tests
+     * brings the wavefront's trips through the node loop from 580 to 380 per search of the 100 000-triangle scene and
+     * costs more than that saves in every trip: 46-50 against 43 ms.) */
+#ifdef BDPT_BVH_STATS
+    unsigned int stat[4] = {0, 0, 0, 0};
+#endif
+    constexpr int kDone = (int)0x80000000;                                /* no leaf reference has this value */
     int cur = S.bvh_root, sp = 0;
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
+#ifdef BDPT_BVH_STATS
+            stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
+#endif
             const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
             const float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
             float t0, t1;
+            if (COUNT) *n_cull += 2;                                      /* box tests */
             const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t0);
             const bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t1);
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
@@ -605,30 +626,37 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
                 stack[sp * 64] = (uint32_t)(first0 ? c1 : c0);
                 sp++;
                 cur = first0 ? c0 : c1;
-                continue;
+            } else if (h0 || h1) {
+                cur = h0 ? c0 : c1;
+            } else if (sp == 0) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = (int)stack[sp * 64];
             }
-            if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
-        } else {
+        }
+        if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0) break;
+        if (cur != kDone) {
+#ifdef BDPT_BVH_STATS
+            stat[2]++; if (BDPT_BVH_FIRST_LANE) stat[3]++;
+#endif
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf & 0x0FFFFFFFu, count = (leaf >> 28) + 1u;
             for (uint32_t k = 0; k < count; k++) {
-                const float4 c = S.bvh_leaf_sph[first + k];
-                const float u = clm_fma(c.z, d.z, clm_fma(c.y, d.y, clm_fma(c.x, d.x, -od)));
-                const float t = clm_fma(c.z, o2.z, clm_fma(c.y, o2.y, clm_fma(c.x, o2.x, c.w)));
-                const float e = clm_fma(-u, u, t);
-                if (COUNT) ++*n_cull;
-                if (!(e > bound)) {
-                    const int i = (int)S.bvh_leaf_tri[first + k];
-                    test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
-                    if (COUNT) ++*n_exact;
-                }
+                const int i = (int)S.bvh_leaf_tri[first + k];
+                test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
             }
-            reach = __builtin_sqrtf(b.d2) * 1.0001f;
+            if (COUNT) *n_exact += count;
+            reach = __builtin_sqrtf(b.d2) * per_length;
+            if (sp == 0) cur = kDone;
+            else { sp--; cur = (int)stack[sp * 64]; }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (int)stack[sp * 64];
     }
+#ifdef BDPT_BVH_STATS
+    for (int k = 0; k < 4; k++) BDPT_BVH_STAT(k, stat[k]);
+    BDPT_BVH_STAT(4, 1);
+    if (BDPT_BVH_FIRST_LANE) BDPT_BVH_STAT(5, 1);
+#endif
     return finish_hit(S, b, d);
 }
 
@@ -820,7 +848,10 @@ template <bool AOV, bool COUNT, int MODE, bool ALT>
 #ifndef BDPT_LDS2_WAVES
 #define BDPT_LDS2_WAVES 6
 #endif
-__global__ __launch_bounds__(BDPT_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
+#ifndef BDPT_BVH_WAVES
+#define BDPT_BVH_WAVES 6
+#endif
+__global__ __launch_bounds__(BDPT_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6)))
 void bdpt_direct_kernel(const bdpt_kargs K)
 {
     if (MODE == MODE_LDS) lds_fill_scene<false>(K.scene);   /* every thread of the workgroup, before any early exit */
@@ -1499,7 +1530,7 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
     }
     if (MODE == bdpt::MODE_BVH) {
         /* a hierarchy has leaves; one with inner nodes has those too */
-        if (K.scene.bvh_root != BDPT_BVH_NONE && (!K.scene.bvh_leaf_sph || !K.scene.bvh_leaf_tri || (K.scene.bvh_root >= 0 && !K.scene.bvh_nodes))) return hipErrorInvalidValue;
+        if (K.scene.bvh_root != BDPT_BVH_NONE && (!K.scene.bvh_leaf_tri || (K.scene.bvh_root >= 0 && !K.scene.bvh_nodes))) return hipErrorInvalidValue;
         if (K.scene.bvh_n_brute > 0 && !K.scene.bvh_brute) return hipErrorInvalidValue;
         lds = (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t);                 /* one wavefront per workgroup, its lanes' stacks */
     }
@@ -1798,5 +1829,16 @@ extern "C" int bdpt_phase_clocks(unsigned long long out[12], int reset)
         e = hipMemcpyToSymbol(HIP_SYMBOL(bdpt::bdpt_phase_clocks_dev), zero, sizeof zero);
     }
     return e == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef BDPT_BVH_STATS
+/* reads and clears the walk's statistics (tools/bvh_stats.py; builds with -DBDPT_BVH_STATS only) */
+extern "C" void bdpt_bvh_stats_read(unsigned long long *out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(bdpt::bvh_stats), 8 * sizeof(unsigned long long));
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(bdpt::bvh_stats), zero, sizeof zero);
 }
 #endif

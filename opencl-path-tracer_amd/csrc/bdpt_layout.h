@@ -83,10 +83,9 @@ struct bdpt_dev_scene {
     const uint32_t *tri_surf;   /* [n_triangles] */
     const float4 *surf;         /* [n_surfaces * 2] */
     int n_spheres, n_planes, n_triangles, n_surfaces;
-    /* hierarchy over the triangles' bounding spheres (bdpt_bvh.h); bvh_nodes null = the scene has none */
+    /* hierarchy of boxes over the triangles (bdpt_bvh.h) */
     const float4 *bvh_nodes;    /* [inner nodes * BDPT_BVH_NODE_F4] */
-    const float4 *bvh_leaf_sph; /* [triangles in the hierarchy] (c.xyz, w) in leaf order */
-    const uint32_t *bvh_leaf_tri;   /* their triangle indices */
+    const uint32_t *bvh_leaf_tri;   /* [triangles in the hierarchy] triangle indices in leaf order */
     const uint32_t *bvh_brute;  /* [bvh_n_brute] triangles every ray tests in full, ascending */
     int bvh_root, bvh_n_brute;
 };

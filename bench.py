@@ -494,6 +494,17 @@ def main():
                     line[names[sched]] = sub
             ctx.set_path_scheduling(bdpt.PATHS_AUTO)
             out["stream_mode"] = line
+        # the many-triangle scene through the exhaustive search as well (every ray meets every triangle's bounding
+        # sphere: what this configuration was defined on), beside the hierarchy walk the library chooses by itself
+        if args.workload == "c4" and world == 1 and variant == bdpt.KERNEL_BVH:
+            ctx.set_params(bdpt.default_params(rng_mode=bdpt.RNG_STRIDED, accum_mode=bdpt.ACCUM_SUM, kernel_variant=bdpt.KERNEL_TILED, sample_order=order))
+            ctx.set_camera(scene.camera)
+            ctx.render(SPP)
+            out["exhaustive_search"] = {"kernel_variant": "TILED", "kernel_ms": round(ctx.last_launch_ms(), 3),
+                                        "mpaths_per_s": round(W * H * SPP / ctx.last_launch_ms() / 1e3, 2),
+                                        "what": "the same launch with every triangle's bounding sphere tested for every ray (kernel_variant TILED), one launch"}
+            ctx.set_params(bench_params)
+            ctx.set_camera(scene.camera)
             ctx.set_params(bench_params)
 
     # The second half of the headline metric: wall time from a camera reset until the accumulated image is within

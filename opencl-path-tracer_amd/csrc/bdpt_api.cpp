@@ -965,9 +965,12 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
      * library runs them so from BDPT_CPOOL_AUTO_MIN_SPP samples on (1080p Cornell box, sequential generator, running
      * mean: 1 sample 0.25 against 0.20 ms, 4 samples 0.79 against 0.89, 64 samples 9.3 against 9.6, 1024 samples 118
      * against 134).  Its runs cost less to start than the per-lane kernels' (the image is updated in place), so a
-     * launch may be cut into twice as many. */
+     * launch may be cut into twice as many.  Not over the hierarchy walk unless asked for: that kernel lives on the
+     * number of resident wavefronts, and the pool's LDS costs it three of 24 (100 000 triangles, 64 samples: 1344
+     * against 1310 ms). */
     const bool by_class = ctx->params.integrator != BDPT_INTEGRATOR_PATH_TRACE && bdpt_class_pool_supported(K, variant) &&
-                          (ctx->path_scheduling == BDPT_PATHS_BY_CLASS || (ctx->path_scheduling == BDPT_PATHS_AUTO && spp >= BDPT_CPOOL_AUTO_MIN_SPP));
+                          (ctx->path_scheduling == BDPT_PATHS_BY_CLASS ||
+                           (ctx->path_scheduling == BDPT_PATHS_AUTO && spp >= BDPT_CPOOL_AUTO_MIN_SPP && variant != BDPT_KERNEL_BVH));
     /* Sliced launch (slice_begin in bdpt_kernels.hip): runs short enough that the launch does not end with a long
      * drain, long enough that the per-run reload of the pixel state does not show (1080p Cornell box: 64 samples
      * 10.4 -> 9.8 ms as 8 runs, 256 samples 47.5 -> 42.2 ms as 16, 1024 samples 175 -> 158 ms as 16, no gain from

@@ -47,7 +47,7 @@ static_assert(BDPT_CPOOL_SLOTS % 64 == 0 && BDPT_CPOOL_PER_LANE <= 8, "a lane lo
 /* slot word: class of the pixel's next sample (bits 0-7; 0 = no more samples in this run) | samples taken in this run << 8 */
 
 template <bool AOV, bool COUNT, int MODE, bool ALT>
-__global__ __launch_bounds__(BDPT_CPOOL_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : 6)))
+__global__ __launch_bounds__(BDPT_CPOOL_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6)))
 void bdpt_class_pool_kernel(const bdpt_kargs K)
 {
     constexpr int PER = BDPT_CPOOL_PER_LANE;
@@ -58,9 +58,10 @@ void bdpt_class_pool_kernel(const bdpt_kargs K)
     const Slice sl = slice_begin(K);
     if (sl.abandoned) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = K.block >> 6;
-    /* behind the scene and the lanes' parked eye vertices (lane_park) */
+    /* behind the scene and the lanes' parked eye vertices (lane_park), or behind the stacks of the hierarchy walk */
     const LdsLayout L = MODE == MODE_LDS2 ? lds_layout<true>(S) : lds_layout<false>(S);
-    const int base_f4 = MODE == MODE_DIRECT ? 0 : L.ids + L.n_ids / 4 + (int)blockDim.x * BDPT_PARK_F4;
+    const int base_f4 = MODE == MODE_DIRECT ? 0 : MODE == MODE_BVH ? (int)(blockDim.x >> 6) * (BDPT_BVH_STACK * 64 / 4)     /* behind the walk's stacks */
+                                                : L.ids + L.n_ids / 4 + (int)blockDim.x * BDPT_PARK_F4;
     uint32_t *const words = (uint32_t *)(bdpt_lds + base_f4 + wv * BDPT_CPOOL_WAVE_F4);      /* [64][BDPT_CPOOL_LANE_WORDS] */
     uint32_t *const list = words + (64 * BDPT_CPOOL_LANE_WORDS + 3) / 4 * 4;
     constexpr int LW = BDPT_CPOOL_LANE_WORDS;

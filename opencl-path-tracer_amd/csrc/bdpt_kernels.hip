@@ -1653,10 +1653,10 @@ hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool cou
  * order, with the per-pixel kernels' workgroup shapes (one wavefront where 24 workgroups fit a compute unit, else two). */
 bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant)
 {
-    if (variant != BDPT_KERNEL_DIRECT && variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2) return false;
+    if (variant != BDPT_KERNEL_DIRECT && variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2 && variant != BDPT_KERNEL_BVH) return false;
     if (K.reorder != 0 || K.tile_stride > 1 || K.max_l > BDPT_CPOOL_MAX_CLASS) return false;
     if (variant == BDPT_KERNEL_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return false;
-    return variant == BDPT_KERNEL_DIRECT || bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
+    return variant == BDPT_KERNEL_DIRECT || variant == BDPT_KERNEL_BVH || bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
 }
 
 /* Threads per workgroup and bytes of LDS of such a launch: the fewest wavefronts per workgroup (they share one copy of
@@ -1664,9 +1664,9 @@ bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant)
 static void class_pool_shape(const bdpt_kargs &K, int variant, int &block, size_t &lds)
 {
     const size_t pool = (size_t)BDPT_CPOOL_WAVE_F4 * sizeof(float4);
-    if (variant == BDPT_KERNEL_DIRECT) {
+    if (variant == BDPT_KERNEL_DIRECT || variant == BDPT_KERNEL_BVH) {
         block = 64;
-        lds = pool;
+        lds = pool + (variant == BDPT_KERNEL_BVH ? (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t) : 0);   /* the hierarchy walk's stacks come first */
         return;
     }
     const size_t scene = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);
@@ -1682,7 +1682,7 @@ static hipError_t launch_class_pool(bdpt_kargs K, bool aov, bool count, hipStrea
 {
     if (K.rw <= 0 || K.rh <= 0 || K.spp <= 0) return hipErrorInvalidValue;
     size_t lds = 0;
-    class_pool_shape(K, MODE == bdpt::MODE_LDS2 ? BDPT_KERNEL_LDS2 : MODE == bdpt::MODE_LDS ? BDPT_KERNEL_LDS : BDPT_KERNEL_DIRECT, K.block, lds);
+    class_pool_shape(K, MODE == bdpt::MODE_LDS2 ? BDPT_KERNEL_LDS2 : MODE == bdpt::MODE_LDS ? BDPT_KERNEL_LDS : MODE == bdpt::MODE_BVH ? BDPT_KERNEL_BVH : BDPT_KERNEL_DIRECT, K.block, lds);
     K.pool_w = BDPT_CPOOL_W;
     K.pool_rows = BDPT_CPOOL_ROWS;
     dim3 grid;
@@ -1712,6 +1712,7 @@ hipError_t bdpt_launch_class_pool(const bdpt_kargs &K, int variant, bool aov, bo
     if (!bdpt_class_pool_supported(K, variant)) return hipErrorInvalidValue;
     if (variant == BDPT_KERNEL_LDS2) return launch_class_pool<bdpt::MODE_LDS2>(K, aov, count, stream);
     if (variant == BDPT_KERNEL_LDS) return launch_class_pool<bdpt::MODE_LDS>(K, aov, count, stream);
+    if (variant == BDPT_KERNEL_BVH) return launch_class_pool<bdpt::MODE_BVH>(K, aov, count, stream);
     return launch_class_pool<bdpt::MODE_DIRECT>(K, aov, count, stream);
 }
 

@@ -1,0 +1,53 @@
+"""The hierarchy walk of the many-triangle kernel (BDPT_KERNEL_BVH, csrc/bdpt_bvh.h): a ray visits the triangles near
+its line in whatever order the boxes come, and must still return the reference's hit -- the nearest, and among equally
+near ones the lowest index (kernel0.cl:434-449 walks in index order with a strict "<").  Scenes made to trip it
+(tests/bvh_scenes.py) against the CPU oracle, every id, count and bit; and the statements the builder makes about its
+own output."""
+import numpy as np
+import pytest
+
+import bvh_scenes
+from test_gpu_parity import _compare, _pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", bvh_scenes.KINDS)
+@pytest.mark.parametrize("n", [3, 400])
+def test_hierarchy_returns_the_reference_hit(bdpt, oracle, kind, n):
+    rng = np.random.default_rng(bvh_scenes.KINDS.index(kind) * 100 + n)
+    scene = bvh_scenes.scene_for(bdpt, rng, kind, n)
+    W, H = 48, 36
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=7 + n, kernel_variant=bdpt.KERNEL_BVH)
+    for s in range(2):
+        ctx.render(3)
+        assert ctx.last_launch_variant() == bdpt.KERNEL_BVH
+        oracle.render(st, scene, scene.camera, p, 3, n_threads=8)
+        _compare(bdpt, ctx, st, "%s %d launch %d:" % (kind, n, s))
+    ctx.close()
+
+
+def test_equal_distances_go_to_the_lowest_index(bdpt, oracle):
+    """Forty copies of one large triangle that faces the camera, in shuffled order among other triangles: every eye
+    ray that hits the stack must report the copy with the lowest index."""
+    rng = np.random.default_rng(5)
+    scene = bvh_scenes.scene_for(bdpt, rng, "plain", 200)
+    sheet = np.zeros(40, bdpt.triangle_dtype)
+    corners = np.float32([(1.0, -1.2, 1.5), (1.0, -1.2, -1.5), (1.0, 1.6, 0.0)])     # the camera looks along -x
+    sheet["p0"][:, :3], sheet["p1"][:, :3], sheet["p2"][:, :3] = corners
+    sheet["surface"] = 1
+    tri = np.concatenate([scene.triangles[12:], sheet])
+    rng.shuffle(tri)
+    scene.triangles = np.concatenate([scene.triangles[:12], tri])
+    copies = [i for i in range(len(scene.triangles)) if all(np.array_equal(scene.triangles[f][i, :3], c) for f, c in zip(("p0", "p1", "p2"), corners))]
+    assert len(copies) == 40
+    W, H = 64, 48
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=11, kernel_variant=bdpt.KERNEL_BVH)
+    ctx.render(2)
+    oracle.render(st, scene, scene.camera, p, 2, n_threads=8)
+    _compare(bdpt, ctx, st, "stack of copies:")
+    eye = ctx.read_aov(bdpt.AOV_EYE_HIT)
+    on_stack = np.isin(eye[..., 1], copies) & (eye[..., 0] == 2)
+    assert on_stack.sum() > 50
+    assert set(np.unique(eye[..., 1][on_stack])) == {min(copies)}
+    ctx.close()

@@ -12,7 +12,7 @@ from test_gpu_parity import _compare, _pair
 
 pytestmark = pytest.mark.gpu
 
-DIRECT, LDS, LDS2 = 1, 3, 5
+DIRECT, LDS, LDS2, BVH = 1, 3, 5, 6
 
 
 def _by_class_pair(bdpt, oracle, scene, W, H, **kw):
@@ -21,7 +21,7 @@ def _by_class_pair(bdpt, oracle, scene, W, H, **kw):
     return ctx, st, p
 
 
-@pytest.mark.parametrize("variant", [DIRECT, LDS, LDS2])
+@pytest.mark.parametrize("variant", [DIRECT, LDS, LDS2, BVH])
 @pytest.mark.parametrize("chunks", [1, 3, 0])
 def test_by_class_stream_mode_matches_the_oracle(bdpt, oracle, variant, chunks):
     """Cornell box on a frame that is no multiple of a wavefront's 16 x 8 pixels, the reference's mode, several

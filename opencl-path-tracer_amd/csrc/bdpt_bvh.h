@@ -27,15 +27,25 @@
  * few that are far larger than the rest (the walls of a room around a soup of small triangles: their boxes would
  * swallow every node above them) are kept out of the hierarchy in a short list that every ray tests in full.
  *
- * Built by median split of the longest axis of the centres' bounds, so the depth is ceil(log2(n / leaf size)) + 1
- * whatever the scene looks like, and the per-lane stack of the walk (BDPT_BVH_STACK entries) is known to suffice.
+ * Built by median split of the longest axis of the centres' bounds (depth ceil(log2(n / leaf size)) + 1 whatever
+ * the scene looks like), then folded into nodes of four children.  A walk pushes up to three entries per level on its
+ * per-lane stack of BDPT_BVH_STACK entries; a lane whose stack would run over leaves the walk and meets every triangle
+ * instead (bdpt_kernels.hip), so any depth is safe.
  */
 #ifndef BDPT_BVH_H
 #define BDPT_BVH_H
 
 #include "bdpt_layout.h"
 
+#ifndef BDPT_BVH_WIDE
+#define BDPT_BVH_WIDE 4           /* children per inner node: 2 or 4 */
+#endif
+#if BDPT_BVH_WIDE == 2
 #define BDPT_BVH_NODE_F4 4        /* (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (child0, child1, -, -) */
+#else
+#define BDPT_BVH_NODE_F4 8        /* lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of the four children, their references, padding: one 128-byte line */
+#endif
+#define BDPT_BVH_EMPTY ((int)0x80000000)   /* reference of a child slot that holds nothing (its box is inside out); no leaf has this value */
 #ifndef BDPT_BVH_LEAF_MAX
 #define BDPT_BVH_LEAF_MAX 2       /* triangles per leaf */
 #endif
@@ -102,7 +112,9 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
     if (out.brute.size() > BDPT_BVH_BRUTE_MAX) return false;
     if (idx.empty()) return true;
     out.leaf_tri.reserve(idx.size());
-    out.nodes.reserve(idx.size() / 2 * BDPT_BVH_NODE_F4 + BDPT_BVH_NODE_F4);
+    struct Pair { Box b[2]; int ref[2]; };
+    std::vector<Pair> pairs;                               /* the binary tree */
+    pairs.reserve(idx.size());
 
     struct Ref { int ref; Box b; int depth; };
     /* recursion on [first, last) of idx; depth-first, so a subtree's nodes and leaves are contiguous */
@@ -111,6 +123,7 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
         std::vector<Box> &box;
         std::vector<uint32_t> &idx;
         bdpt_bvh_host &out;
+        std::vector<Pair> &pairs;
         Ref build(size_t first, size_t last)
         {
             Ref r;
@@ -142,28 +155,83 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
                 const float cb = axis == 0 ? bound[b].x : axis == 1 ? bound[b].y : bound[b].z;
                 return ca < cb || (ca == cb && a < b);
             });
-            const size_t node = out.nodes.size() / BDPT_BVH_NODE_F4;
-            out.nodes.resize(out.nodes.size() + BDPT_BVH_NODE_F4);
+            const size_t node = pairs.size();
+            pairs.emplace_back();
             const Ref a = build(first, mid), b = build(mid, last);
-            float4 *q = &out.nodes[node * BDPT_BVH_NODE_F4];
-            q[0] = make_float4(a.b.lo[0], a.b.lo[1], a.b.lo[2], a.b.hi[0]);
-            q[1] = make_float4(a.b.hi[1], a.b.hi[2], b.b.lo[0], b.b.lo[1]);
-            q[2] = make_float4(b.b.lo[2], b.b.hi[0], b.b.hi[1], b.b.hi[2]);
-            float fa, fb;
-            static_assert(sizeof(float) == sizeof(int), "child references travel as the bits of a float");
-            std::memcpy(&fa, &a.ref, 4);
-            std::memcpy(&fb, &b.ref, 4);
-            q[3] = make_float4(fa, fb, 0.0f, 0.0f);
+            pairs[node].b[0] = a.b; pairs[node].b[1] = b.b;
+            pairs[node].ref[0] = a.ref; pairs[node].ref[1] = b.ref;
             for (int k = 0; k < 3; k++) { r.b.lo[k] = std::min(a.b.lo[k], b.b.lo[k]); r.b.hi[k] = std::max(a.b.hi[k], b.b.hi[k]); }
             r.ref = (int)node;
             r.depth = 1 + std::max(a.depth, b.depth);
             return r;
         }
-    } builder{bound, box, idx, out};
+    } builder{bound, box, idx, out, pairs};
     if (idx.size() >= ((size_t)1 << 28)) return false;
     const Ref root = builder.build(0, idx.size());
-    out.root = root.ref;
     out.depth = root.depth;
+    static_assert(sizeof(float) == sizeof(int), "child references travel as the bits of a float");
+    auto as_float = [](int ref) { float f; std::memcpy(&f, &ref, 4); return f; };
+#if BDPT_BVH_WIDE == 2
+    out.root = root.ref;
+    out.nodes.resize(pairs.size() * BDPT_BVH_NODE_F4);
+    for (size_t n = 0; n < pairs.size(); n++) {
+        const Box &a = pairs[n].b[0], &b = pairs[n].b[1];
+        float4 *q = &out.nodes[n * BDPT_BVH_NODE_F4];
+        q[0] = make_float4(a.lo[0], a.lo[1], a.lo[2], a.hi[0]);
+        q[1] = make_float4(a.hi[1], a.hi[2], b.lo[0], b.lo[1]);
+        q[2] = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
+        q[3] = make_float4(as_float(pairs[n].ref[0]), as_float(pairs[n].ref[1]), 0.0f, 0.0f);
+    }
     return root.depth <= BDPT_BVH_STACK;
+#else
+    /* four children per node: a node's children are replaced by their own children, the one with the largest box
+     * first, until there are four or only leaves are left */
+    if (root.ref < 0) { out.root = root.ref; return true; }
+    struct Wide {
+        const std::vector<Pair> &pairs;
+        bdpt_bvh_host &out;
+        float (*as_float)(int);
+        static double area(const Box &b) {
+            const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+            return x * y + y * z + z * x;
+        }
+        int collapse(int pair)
+        {
+            Box b[4];
+            int ref[4], n = 2;
+            b[0] = pairs[pair].b[0]; b[1] = pairs[pair].b[1];
+            ref[0] = pairs[pair].ref[0]; ref[1] = pairs[pair].ref[1];
+            while (n < 4) {
+                int pick = -1;
+                for (int k = 0; k < n; k++)
+                    if (ref[k] >= 0 && (pick < 0 || area(b[k]) > area(b[pick]))) pick = k;
+                if (pick < 0) break;
+                const Pair &p = pairs[ref[pick]];
+                b[pick] = p.b[0]; ref[pick] = p.ref[0];
+                b[n] = p.b[1]; ref[n] = p.ref[1];
+                n++;
+            }
+            const size_t node = out.nodes.size() / BDPT_BVH_NODE_F4;
+            out.nodes.resize(out.nodes.size() + BDPT_BVH_NODE_F4);
+            for (int k = n; k < 4; k++) {
+                for (int a = 0; a < 3; a++) { b[k].lo[a] = INFINITY; b[k].hi[a] = -INFINITY; }
+                ref[k] = BDPT_BVH_EMPTY;
+            }
+            for (int k = 0; k < n; k++)
+                if (ref[k] >= 0) ref[k] = collapse(ref[k]);
+            float4 *q = &out.nodes[node * BDPT_BVH_NODE_F4];
+            for (int a = 0; a < 3; a++) {
+                q[a] = make_float4(b[0].lo[a], b[1].lo[a], b[2].lo[a], b[3].lo[a]);
+                q[3 + a] = make_float4(b[0].hi[a], b[1].hi[a], b[2].hi[a], b[3].hi[a]);
+            }
+            q[6] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
+            q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            return (int)node;
+        }
+    } wide{pairs, out, +as_float};
+    out.nodes.reserve(pairs.size() / 2 * BDPT_BVH_NODE_F4);
+    out.root = wide.collapse(root.ref);
+    return true;                                             /* a walk whose stack runs full finishes without the hierarchy */
+#endif
 }
 #endif

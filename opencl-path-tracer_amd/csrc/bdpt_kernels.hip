@@ -607,14 +607,18 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
 #ifdef BDPT_BVH_STATS
     unsigned int stat[4] = {0, 0, 0, 0};
 #endif
-    constexpr int kDone = (int)0x80000000;                                /* no leaf reference has this value */
+    constexpr int kDone = BDPT_BVH_EMPTY;                                 /* no leaf reference has this value */
     int cur = S.bvh_root, sp = 0;
+#if BDPT_BVH_WIDE == 4
+    bool overflow = false;                                                /* the stack ran full: this lane finishes without the hierarchy */
+#endif
     for (;;) {
         while (cur >= 0) {
 #ifdef BDPT_BVH_STATS
             stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
 #endif
             const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
+#if BDPT_BVH_WIDE == 2
             const float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
             float t0, t1;
             if (COUNT) *n_cull += 2;                                      /* box tests */
@@ -634,6 +638,37 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
                 sp--;
                 cur = (int)stack[sp * 64];
             }
+#else
+            const float4 lx = node[0], ly = node[1], lz = node[2], hx = node[3], hy = node[4], hz = node[5], rf = node[6];
+            if (COUNT) *n_cull += 4;                                      /* box tests */
+            float t0, t1, t2, t3;
+            const bool h0 = slab(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0), h1 = slab(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1);
+            const bool h2 = slab(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2), h3 = slab(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3);
+            /* the children this ray visits, nearest first: (entry parameter, reference) pairs through a sorting
+             * network; a child that is not visited (an empty slot's box is inside out: never hit) sorts last */
+            float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY, k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
+            int r0 = h0 ? __float_as_int(rf.x) : kDone, r1 = h1 ? __float_as_int(rf.y) : kDone, r2 = h2 ? __float_as_int(rf.z) : kDone,
+                r3 = h3 ? __float_as_int(rf.w) : kDone;
+            auto order = [](float &ka, int &ra, float &kb, int &rb) {
+                const bool swap = kb < ka;
+                const float k = swap ? kb : ka; kb = swap ? ka : kb; ka = k;
+                const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
+            };
+            order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
+            const int more = (r1 != kDone) + (r2 != kDone) + (r3 != kDone);
+            if (sp + more > BDPT_BVH_STACK) { overflow = true; cur = kDone; break; }
+            if (r3 != kDone) { stack[sp * 64] = (uint32_t)r3; sp++; }
+            if (r2 != kDone) { stack[sp * 64] = (uint32_t)r2; sp++; }
+            if (r1 != kDone) { stack[sp * 64] = (uint32_t)r1; sp++; }
+            if (r0 != kDone) {
+                cur = r0;
+            } else if (sp == 0) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = (int)stack[sp * 64];
+            }
+#endif
         }
         if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0) break;
         if (cur != kDone) {
@@ -652,6 +687,19 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
             else { sp--; cur = (int)stack[sp * 64]; }
         }
     }
+#if BDPT_BVH_WIDE == 4
+    /* a lane whose stack ran full (a ray that passes all four boxes of node after node: the bound is three entries
+     * per level) meets every triangle of the hierarchy instead; the comparison by (distance, index) makes a second
+     * meeting with a triangle harmless */
+    if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
+        for (int i = 0; i < S.n_triangles; i++) {
+            const size_t r = (size_t)i * BDPT_TRI_F4;
+            const float4 q0 = uload(S.tri, r), q1 = uload(S.tri, r + 1), q2 = uload(S.tri, r + 2), q3 = uload(S.tri, r + 3), q4 = uload(S.tri, r + 4);
+            const float4 rec[6] = {q0, q1, q2, q3, q4, uload(S.tri, r + 5)};
+            if (overflow) test_triangle_unordered(b, rec, i, skip_t, o, d);
+        }
+    }
+#endif
 #ifdef BDPT_BVH_STATS
     for (int k = 0; k < 4; k++) BDPT_BVH_STAT(k, stat[k]);
     BDPT_BVH_STAT(4, 1);

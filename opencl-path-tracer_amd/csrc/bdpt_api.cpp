@@ -66,6 +66,7 @@ struct bdpt_ctx {
     float4 *d_bvh_nodes = nullptr;
     uint32_t *d_bvh_leaf_tri = nullptr, *d_bvh_brute = nullptr;
     int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0;
+    int bvh_stack_limit = BDPT_BVH_STACK;   /* entries of the walk's stack a lane may use (BDPT_BVH_STACK_LIMIT) */
     bool have_bvh = false;              /* false: the scene cannot have one (bdpt_bvh_build), BDPT_KERNEL_BVH is refused */
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -236,6 +237,12 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
     if (const char *env = std::getenv("BDPT_PATH_SCHEDULING")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= BDPT_PATHS_AUTO && v <= BDPT_PATHS_BY_CLASS) ctx->path_scheduling = (int)v;
+    }
+    /* BDPT_BVH_STACK_LIMIT in the environment: the hierarchy walk's per-lane stack, in entries, for every context (a
+     * testing aid: with a limit of two or three nearly every walk runs over and finishes without the hierarchy) */
+    if (const char *env = std::getenv("BDPT_BVH_STACK_LIMIT")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= BDPT_BVH_STACK) ctx->bvh_stack_limit = (int)v;
     }
     const size_t npix = (size_t)width * height;
     auto bail = [&](hipError_t err, const char *what) {
@@ -843,7 +850,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
     K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
-    K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute;
+    K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute; K.scene.bvh_stack_limit = ctx->bvh_stack_limit;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;

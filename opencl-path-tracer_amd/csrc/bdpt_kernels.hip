@@ -656,7 +656,7 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
             };
             order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
             const int more = (r1 != kDone) + (r2 != kDone) + (r3 != kDone);
-            if (sp + more > BDPT_BVH_STACK) { overflow = true; cur = kDone; break; }
+            if (sp + more > S.bvh_stack_limit) { overflow = true; cur = kDone; break; }
             if (r3 != kDone) { stack[sp * 64] = (uint32_t)r3; sp++; }
             if (r2 != kDone) { stack[sp * 64] = (uint32_t)r2; sp++; }
             if (r1 != kDone) { stack[sp * 64] = (uint32_t)r1; sp++; }
@@ -1580,6 +1580,7 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
         /* a hierarchy has leaves; one with inner nodes has those too */
         if (K.scene.bvh_root != BDPT_BVH_NONE && (!K.scene.bvh_leaf_tri || (K.scene.bvh_root >= 0 && !K.scene.bvh_nodes))) return hipErrorInvalidValue;
         if (K.scene.bvh_n_brute > 0 && !K.scene.bvh_brute) return hipErrorInvalidValue;
+        if (K.scene.bvh_stack_limit < 1 || K.scene.bvh_stack_limit > BDPT_BVH_STACK) return hipErrorInvalidValue;
         lds = (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t);                 /* one wavefront per workgroup, its lanes' stacks */
     }
     dim3 grid;

@@ -51,3 +51,19 @@ def test_equal_distances_go_to_the_lowest_index(bdpt, oracle):
     assert on_stack.sum() > 50
     assert set(np.unique(eye[..., 1][on_stack])) == {min(copies)}
     ctx.close()
+
+
+def test_a_walk_whose_stack_runs_over_finishes_without_the_hierarchy(bdpt, oracle, monkeypatch):
+    """A ray can pass all four boxes of node after node and need three stack entries per level.  With the stack limited
+    to two entries (BDPT_BVH_STACK_LIMIT, read when a context is created) most walks of this scene run over and meet
+    every triangle instead: the same bits."""
+    monkeypatch.setenv("BDPT_BVH_STACK_LIMIT", "2")
+    rng = np.random.default_rng(21)
+    scene = bvh_scenes.scene_for(bdpt, rng, "duplicates", 300)
+    W, H = 40, 30
+    ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=3, kernel_variant=bdpt.KERNEL_BVH)
+    ctx.render(4)
+    assert ctx.last_launch_variant() == bdpt.KERNEL_BVH
+    oracle.render(st, scene, scene.camera, p, 4, n_threads=8)
+    _compare(bdpt, ctx, st, "stack of two entries:")
+    ctx.close()

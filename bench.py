@@ -364,7 +364,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%s, %dx%d, %d spp per GPU per step, exhaustive closest hit" % (scene_name, W, H, SPP),
+            "workload": "%s, %dx%d, %d spp per GPU per step, %s" % (scene_name, W, H, SPP, "closest hit through a hierarchy over the triangles (same hits as the exhaustive search)" if variant == bdpt.KERNEL_BVH else "exhaustive closest hit"),
             "rng_mode": "strided", "accumulate": "sum", "sample_order": {"auto": "adaptive (roulette classes for pixels whose first eye ray reaches a surface)", "index": "index",
                              "class": "roulette class", "adaptive": "adaptive"}[args.order],
             "kernel_variant": variant_name,
@@ -420,6 +420,8 @@ def main():
         avg_s = sum(launch_ms) / len(launch_ms) / 1e3
         achieved = flops / avg_s / 1e12
         traffic = recorded("hbm_traffic.json", "%s/%dx%d" % (args.workload, W, H))
+        if args.workload == "c4" and variant != bdpt.KERNEL_TILED:
+            traffic = None                                   # the figures on file are the exhaustive kernel's
         traffic_bytes = None if traffic is None else traffic["fixed"] + traffic["per_spp"] * SPP + traffic.get("per_extra_run", 0) * (weak_chunks - 1)
         traffic_source = None if traffic is None else traffic.get("source", "profiles/hbm_traffic.json: rocprofv3 --pmc passes of an earlier run of this command, not this run")
         if world == 1 and not args.no_traffic_pass:

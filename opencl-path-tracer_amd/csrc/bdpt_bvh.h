@@ -47,7 +47,10 @@
 #endif
 #define BDPT_BVH_EMPTY ((int)0x80000000)   /* reference of a child slot that holds nothing (its box is inside out); no leaf has this value */
 #ifndef BDPT_BVH_LEAF_MAX
-#define BDPT_BVH_LEAF_MAX 2       /* triangles per leaf */
+#define BDPT_BVH_LEAF_MAX 1       /* triangles per leaf */
+#endif
+#ifndef BDPT_BVH_WAIT
+#define BDPT_BVH_WAIT 4           /* lanes waiting at leaves that end the walk's node loop for their wavefront */
 #endif
 #ifndef BDPT_BVH_STACK
 #define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack = deepest tree the device accepts */

@@ -599,11 +599,13 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
         const float in = __builtin_fmaxf(t0 * 0.99999f, 0.0f), out = __builtin_fminf(t1 * 1.00001f, reach);
         return all || !(in > out);
     };
-    /* Two loops in turn, so that the lanes of a wavefront run the same code most of the time: every lane walks down
-     * to its next leaf (or to the end of its walk) and waits there; then all lanes that have one run the reference's
-     * test on their leaf's triangles together.  (Letting a lane collect two, four or eight leaves before the tests
-     * brings the wavefront's trips through the node loop from 580 to 380 per search of the 100 000-triangle scene and
-     * costs more than that saves in every trip: 46-50 against 43 ms.) */
+    /* Two loops in turn, so that the lanes of a wavefront run the same code most of the time: the lanes walk down,
+     * and a lane that reaches a leaf waits there; when BDPT_BVH_WAIT lanes wait (or no lane stands at a node) the
+     * waiting lanes run the reference's test on their leaves' triangles together and the walk goes on.  100 000
+     * triangles, 2 samples: waiting for all lanes 39 ms (a lane idles at its leaf through the others' node steps: 282
+     * trips through the node loop per search where a lane needs 44), for any lane 27.2 (every trip pays for a triangle
+     * test), for four 26.5 (145 trips).  Letting a lane collect two, four or eight leaves in a queue before the tests
+     * costs more in every trip than it saves in trips. */
 #ifdef BDPT_BVH_STATS
     unsigned int stat[4] = {0, 0, 0, 0};
 #endif
@@ -613,7 +615,13 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
     bool overflow = false;                                                /* the stack ran full: this lane finishes without the hierarchy */
 #endif
     for (;;) {
-        while (cur >= 0) {
+        for (;;) {
+            /* the node loop ends for the whole wavefront when no lane stands at a node, or when BDPT_BVH_WAIT lanes
+             * wait at leaves: they would otherwise idle through the others' node steps */
+            const bool at_node = cur >= 0;
+            if (__builtin_amdgcn_ballot_w64(at_node) == 0) break;
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT) break;
+            if (!at_node) continue;
 #ifdef BDPT_BVH_STATS
             stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
 #endif
@@ -671,7 +679,7 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
 #endif
         }
         if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0) break;
-        if (cur != kDone) {
+        if (cur < 0 && cur != kDone) {
 #ifdef BDPT_BVH_STATS
             stat[2]++; if (BDPT_BVH_FIRST_LANE) stat[3]++;
 #endif

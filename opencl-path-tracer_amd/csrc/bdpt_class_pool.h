@@ -44,7 +44,8 @@ namespace bdpt {
 
 static_assert(BDPT_CPOOL_SLOTS % 64 == 0 && BDPT_CPOOL_PER_LANE <= 8, "a lane looks after BDPT_CPOOL_PER_LANE slots");
 
-/* slot word: class of the pixel's next sample (bits 0-7; 0 = no more samples in this run) | samples taken in this run << 8 */
+/* slot word: class of the pixel's next sample (bits 0-7; 0 = the pixel has taken all samples of the launch) | samples of the
+ * launch it has taken << 8 (hence launches of fewer than 2^24 samples per pixel) */
 
 template <bool AOV, bool COUNT, int MODE, bool ALT>
 __global__ __launch_bounds__(BDPT_CPOOL_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6, MODE == MODE_LDS2 ? BDPT_LDS2_WAVES : MODE == MODE_BVH ? BDPT_BVH_WAVES : 6)))

@@ -1711,7 +1711,7 @@ hipError_t bdpt_launch_pool(const bdpt_kargs &K, int variant, bool aov, bool cou
 bool bdpt_class_pool_supported(const bdpt_kargs &K, int variant)
 {
     if (variant != BDPT_KERNEL_DIRECT && variant != BDPT_KERNEL_LDS && variant != BDPT_KERNEL_LDS2 && variant != BDPT_KERNEL_BVH) return false;
-    if (K.reorder != 0 || K.tile_stride > 1 || K.max_l > BDPT_CPOOL_MAX_CLASS) return false;
+    if (K.reorder != 0 || K.tile_stride > 1 || K.max_l > BDPT_CPOOL_MAX_CLASS || K.spp >= (1 << 24)) return false;
     if (variant == BDPT_KERNEL_LDS2 && K.scene.n_triangles > BDPT_CULL_MAX_TRIANGLES) return false;
     return variant == BDPT_KERNEL_DIRECT || variant == BDPT_KERNEL_BVH || bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2) <= BDPT_LDS_SCENE_MAX;
 }

@@ -7,6 +7,27 @@ import numpy as np
 KINDS = ["plain", "cluster", "far", "axis_aligned", "duplicates", "moved"]
 
 
+def mesh(bdpt, rng, cells=40, flat=False):
+    """The Cornell box with a connected surface in it: a cells x cells grid of quads over the floor, two triangles each,
+    heights random (or none: every triangle in one plane, every inner vertex shared by six).  Rays through shared edges
+    and vertices get the same distance from two or more triangles: the lowest index must win."""
+    sc = bdpt.Scene.cornell()
+    xs = np.linspace(-2.5, 2.5, cells + 1, dtype=np.float32)
+    h = np.zeros((cells + 1, cells + 1), np.float32) if flat else (rng.random((cells + 1, cells + 1)) * 0.6).astype(np.float32)
+    tri = np.zeros(2 * cells * cells, bdpt.triangle_dtype)
+    k = 0
+    for i in range(cells):
+        for j in range(cells):
+            p = lambda a, b: (xs[a], np.float32(-1.5) + h[a, b], xs[b])
+            for corners in ((p(i, j), p(i, j + 1), p(i + 1, j)), (p(i + 1, j), p(i, j + 1), p(i + 1, j + 1))):    # facing +y
+                tri["p0"][k, :3], tri["p1"][k, :3], tri["p2"][k, :3] = corners
+                k += 1
+    tri["surface"] = rng.choice([0, 1, 3, 4], len(tri))
+    order = rng.permutation(len(tri))                      # neighbours in space are not neighbours in index
+    sc.triangles = np.concatenate([sc.triangles, tri[order]])
+    return sc
+
+
 def scene_for(bdpt, rng, kind=None, n=None):
     sc = bdpt.Scene.cornell()
     n = int(rng.choice([1, 3, 17, 120, 700, 3000])) if n is None else n

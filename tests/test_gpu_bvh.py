@@ -67,3 +67,21 @@ def test_a_walk_whose_stack_runs_over_finishes_without_the_hierarchy(bdpt, oracl
     oracle.render(st, scene, scene.camera, p, 4, n_threads=8)
     _compare(bdpt, ctx, st, "stack of two entries:")
     ctx.close()
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_connected_mesh_with_shared_edges(bdpt, oracle, flat):
+    """3200 triangles that share every edge and vertex with neighbours of unrelated index (tests/bvh_scenes.py: mesh),
+    seen from above by eye rays and from everywhere by connection and bounce rays: a ray through a shared edge or vertex
+    gets equal distances from several triangles and must report the lowest index, as the reference's in-order walk does."""
+    rng = np.random.default_rng(9)
+    scene = bvh_scenes.mesh(bdpt, rng, 40, flat)
+    W, H = 64, 48
+    for variant in (bdpt.KERNEL_BVH, bdpt.KERNEL_TILED):
+        ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=13, kernel_variant=variant)
+        for s in range(2):
+            ctx.render(4)
+            oracle.render(st, scene, scene.camera, p, 4, n_threads=8)
+            _compare(bdpt, ctx, st, "mesh flat=%s variant %d launch %d:" % (flat, variant, s))
+        assert (st.eye_hit[..., 1][st.eye_hit[..., 0] == 2] >= 12).any()         # the mesh is in view
+        ctx.close()

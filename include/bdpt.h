@@ -364,6 +364,12 @@ int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes);
 int bdpt_last_launch_order_table(const bdpt_ctx *ctx);
 /* BDPT_KERNEL_* that the last launch ran (what AUTO resolved to), 0 before the first launch. */
 int bdpt_last_launch_variant(const bdpt_ctx *ctx);
+/* The hierarchy bdpt_upload_scene built over the scene's triangles (BDPT_KERNEL_BVH): info[0] = inner nodes (four
+ * children each), info[1] = levels of the binary tree it was folded from, info[2] = entries of the walk's per-lane stack a
+ * launch reserves in LDS (256 bytes per wavefront each; deeper walks continue in private memory), info[3] = triangles kept outside the hierarchy, which every ray
+ * tests in full (unbounded and oversized ones).  Returns 1, or 0 when the scene has no hierarchy (none uploaded, or more
+ * than 1024 triangles that nothing bounds).  No reference counterpart. */
+int bdpt_hierarchy_info(const bdpt_ctx *ctx, int info[4]);
 /* How the uploaded scene's triangles are grouped for the two-stage kernel's conservative test: out[0] pairs that
  * are the two halves of a parallelogram, out[1] other pairs in one plane, out[2] triangles on their own, out[3]
  * pairs of parallelograms that are opposite walls of a box (four triangles each, not counted in out[0]); all 0

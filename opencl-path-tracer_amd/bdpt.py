@@ -102,6 +102,7 @@ lib.bdpt_set_num_samples.argtypes = [_vp, C.c_int]
 lib.bdpt_read_accum.argtypes = [_vp, _vp]
 lib.bdpt_write_accum.argtypes = [_vp, _vp]
 lib.bdpt_last_launch_variant.argtypes = [_vp]
+lib.bdpt_hierarchy_info.argtypes = [_vp, C.POINTER(C.c_int)]
 lib.bdpt_set_region.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.bdpt_set_sample_offset.argtypes = [_vp, C.c_int]
 lib.bdpt_set_tile_interleave.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -388,6 +389,13 @@ class Context:
 
     def last_launch_variant(self):
         return lib.bdpt_last_launch_variant(self._h)
+
+    def hierarchy_info(self):
+        """bdpt_hierarchy_info: dict(nodes, depth, stack_entries, outside) of the hierarchy over the scene's triangles, or None"""
+        info = (C.c_int * 4)()
+        if not lib.bdpt_hierarchy_info(self._h, info):
+            return None
+        return dict(nodes=info[0], depth=info[1], stack_entries=info[2], outside=info[3])
 
     def write_accum(self, rgba):
         rgba = _as(rgba, np.float32)

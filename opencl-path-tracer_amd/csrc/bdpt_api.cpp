@@ -65,8 +65,10 @@ struct bdpt_ctx {
     /* hierarchy over the triangles' bounding spheres (bdpt_bvh.h), built by every scene upload that has triangles */
     float4 *d_bvh_nodes = nullptr;
     uint32_t *d_bvh_leaf_tri = nullptr, *d_bvh_brute = nullptr;
-    int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0;
-    int bvh_stack_limit = BDPT_BVH_STACK;   /* entries of the walk's stack a lane may use (BDPT_BVH_STACK_LIMIT) */
+    int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0, bvh_nodes = 0;
+    int bvh_stack_limit = 1;            /* entries of the walk's stack a launch reserves in LDS per lane: what the tree can need, at most BDPT_BVH_STACK */
+    int bvh_stack_total = 1;            /* entries of the private-memory stack of a lane's second walk */
+    int bvh_lds_cap = BDPT_BVH_STACK, bvh_stack_cap = BDPT_BVH_DEEP;   /* BDPT_BVH_STACK_LIMIT in the environment lowers it (testing aid) */
     bool have_bvh = false;              /* false: the scene cannot have one (bdpt_bvh_build), BDPT_KERNEL_BVH is refused */
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -238,11 +240,15 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
         const long v = std::strtol(env, nullptr, 10);
         if (v >= BDPT_PATHS_AUTO && v <= BDPT_PATHS_BY_CLASS) ctx->path_scheduling = (int)v;
     }
-    /* BDPT_BVH_STACK_LIMIT in the environment: the hierarchy walk's per-lane stack, in entries, for every context (a
-     * testing aid: with a limit of two or three nearly every walk runs over and finishes without the hierarchy) */
+    /* BDPT_BVH_STACK_LIMIT=a or a,b in the environment, for every context: the hierarchy walk's stack has at most `a`
+     * entries in LDS and at most `b` (default a) in the private memory of a lane's second walk.  A testing aid: with
+     * "2" nearly every walk runs over twice and finishes without the hierarchy, with "2,64" nearly every walk is
+     * walked a second time. */
     if (const char *env = std::getenv("BDPT_BVH_STACK_LIMIT")) {
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 1 && v <= BDPT_BVH_STACK) ctx->bvh_stack_limit = (int)v;
+        char *end = nullptr;
+        const long a = std::strtol(env, &end, 10);
+        const long b = end && *end == ',' ? std::strtol(end + 1, nullptr, 10) : a;
+        if (a >= 1 && a <= BDPT_BVH_STACK && b >= a && b <= BDPT_BVH_DEEP) { ctx->bvh_lds_cap = (int)a; ctx->bvh_stack_cap = (int)b; }
     }
     const size_t npix = (size_t)width * height;
     auto bail = [&](hipError_t err, const char *what) {
@@ -678,6 +684,9 @@ int bdpt_upload_scene(bdpt_ctx *ctx, const bdpt_sphere *spheres, int n_spheres, 
         ctx->bvh_root = bvh.root;
         ctx->bvh_n_brute = (int)bvh.brute.size();
         ctx->bvh_depth = bvh.depth;
+        ctx->bvh_nodes = (int)(bvh.nodes.size() / BDPT_BVH_NODE_F4);
+        ctx->bvh_stack_total = std::max(1, std::min(bvh.stack_need, ctx->bvh_stack_cap));
+        ctx->bvh_stack_limit = std::min(ctx->bvh_stack_total, ctx->bvh_lds_cap);
     }
     /* AUTO's estimate, in instructions per ray: the LDS variant runs the full test (about 64) on every
      * triangle; the tiled variant runs the sphere test (13) on every triangle and the full test, with
@@ -850,7 +859,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.scene.pln = ctx->d_pln; K.scene.pln_surf = ctx->d_pln_surf;
     K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
-    K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute; K.scene.bvh_stack_limit = ctx->bvh_stack_limit;
+    K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute; K.scene.bvh_stack_limit = ctx->bvh_stack_limit; K.scene.bvh_stack_total = ctx->bvh_stack_total;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;
@@ -1148,6 +1157,16 @@ int bdpt_set_order_scratch_limit(bdpt_ctx *ctx, size_t bytes)
 }
 
 int bdpt_last_launch_variant(const bdpt_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
+
+int bdpt_hierarchy_info(const bdpt_ctx *ctx, int info[4])
+{
+    if (!ctx || !info || !ctx->have_scene || !ctx->have_bvh) return 0;
+    info[0] = ctx->bvh_nodes;
+    info[1] = ctx->bvh_depth;
+    info[2] = ctx->bvh_stack_limit;
+    info[3] = ctx->bvh_n_brute;
+    return 1;
+}
 int bdpt_last_launch_chunks(const bdpt_ctx *ctx) { return ctx ? ctx->last_chunks : 0; }
 
 int bdpt_two_stage_record_counts(const bdpt_ctx *ctx, int out[4])

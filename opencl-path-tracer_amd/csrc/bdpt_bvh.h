@@ -29,8 +29,10 @@
  *
  * Built by median split of the longest axis of the centres' bounds (depth ceil(log2(n / leaf size)) + 1 whatever
  * the scene looks like), then folded into nodes of four children.  A walk pushes up to three entries per level on its
- * per-lane stack of BDPT_BVH_STACK entries; a lane whose stack would run over leaves the walk and meets every triangle
- * instead (bdpt_kernels.hip), so any depth is safe.
+ * per-lane stack; the builder reports the most a walk of this tree can need (stack_need), a launch reserves that much
+ * LDS per lane, up to BDPT_BVH_STACK entries; a lane whose stack would run over walks again with BDPT_BVH_DEEP entries
+ * in its private memory, and if that is not enough either it meets every triangle instead (bdpt_kernels.hip), so any
+ * depth is safe.
  */
 #ifndef BDPT_BVH_H
 #define BDPT_BVH_H
@@ -53,8 +55,9 @@
 #define BDPT_BVH_WAIT 4           /* lanes waiting at leaves that end the walk's node loop for their wavefront */
 #endif
 #ifndef BDPT_BVH_STACK
-#define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack = deepest tree the device accepts */
+#define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack in LDS, at most (a launch reserves what its tree can need) */
 #endif
+#define BDPT_BVH_DEEP 64          /* entries of the stack in a lane's private memory, for the second walk of a lane that ran over */
 #define BDPT_BVH_BRUTE_MAX 1024   /* triangles outside the hierarchy, at most */
 #define BDPT_BVH_BIG_MAX 64       /* of which oversized ones */
 /* a child reference: >= 0 the index of an inner node; < 0 a leaf, ~ref = first entry | (entries - 1) << 28 */
@@ -70,7 +73,8 @@ struct bdpt_bvh_host {
     std::vector<uint32_t> leaf_tri;     /* triangle indices in leaf order */
     std::vector<uint32_t> brute;        /* triangles outside the hierarchy, ascending */
     int root = BDPT_BVH_NONE;
-    int depth = 0;                      /* inner levels above the deepest leaf */
+    int depth = 0;                      /* inner levels of the binary tree above the deepest leaf */
+    int stack_need = 0;                 /* entries of the walk's stack that no ray can exceed */
 };
 
 /* vertex(i, k) = const float * to the three coordinates of vertex k of triangle i; bound[i] = (centroid, w), w = -inf
@@ -185,11 +189,12 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
         q[2] = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
         q[3] = make_float4(as_float(pairs[n].ref[0]), as_float(pairs[n].ref[1]), 0.0f, 0.0f);
     }
+    out.stack_need = root.depth;
     return root.depth <= BDPT_BVH_STACK;
 #else
     /* four children per node: a node's children are replaced by their own children, the one with the largest box
      * first, until there are four or only leaves are left */
-    if (root.ref < 0) { out.root = root.ref; return true; }
+    if (root.ref < 0) { out.root = root.ref; out.stack_need = 1; return true; }
     struct Wide {
         const std::vector<Pair> &pairs;
         bdpt_bvh_host &out;
@@ -198,7 +203,7 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
             const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
             return x * y + y * z + z * x;
         }
-        int collapse(int pair)
+        int collapse(int pair, int &need)
         {
             Box b[4];
             int ref[4], n = 2;
@@ -220,8 +225,10 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
                 for (int a = 0; a < 3; a++) { b[k].lo[a] = INFINITY; b[k].hi[a] = -INFINITY; }
                 ref[k] = BDPT_BVH_EMPTY;
             }
+            int below = 0;
             for (int k = 0; k < n; k++)
-                if (ref[k] >= 0) ref[k] = collapse(ref[k]);
+                if (ref[k] >= 0) { int sub = 0; ref[k] = collapse(ref[k], sub); below = std::max(below, sub); }
+            need = (n - 1) + below;                          /* the other children wait on the stack while one is walked */
             float4 *q = &out.nodes[node * BDPT_BVH_NODE_F4];
             for (int a = 0; a < 3; a++) {
                 q[a] = make_float4(b[0].lo[a], b[1].lo[a], b[2].lo[a], b[3].lo[a]);
@@ -233,7 +240,7 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
         }
     } wide{pairs, out, +as_float};
     out.nodes.reserve(pairs.size() / 2 * BDPT_BVH_NODE_F4);
-    out.root = wide.collapse(root.ref);
+    out.root = wide.collapse(root.ref, out.stack_need);
     return true;                                             /* a walk whose stack runs full finishes without the hierarchy */
 #endif
 }

@@ -492,7 +492,7 @@ BDPT_DEV Hit closest_hit_lds2(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int o
  *
  * The walk: a node holds the boxes of its two children; a child is visited when the ray passes through its box
  * widened by q(o) (bdpt_bvh.h), in front of the origin and not beyond the best hit so far; the nearer child first,
- * the other one pushed on the lane's stack (one column of a [BDPT_BVH_STACK][64] array of LDS per wavefront, so the
+ * the other one pushed on the lane's stack (one column of a [bvh_stack_limit][64] array of LDS per wavefront, so the
  * lanes' accesses never share a bank).  A ray whose numbers are not finite visits every node.                     */
 /* ------------------------------------------------------------------------- */
 
@@ -610,95 +610,105 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
     unsigned int stat[4] = {0, 0, 0, 0};
 #endif
     constexpr int kDone = BDPT_BVH_EMPTY;                                 /* no leaf reference has this value */
-    int cur = S.bvh_root, sp = 0;
-#if BDPT_BVH_WIDE == 4
-    bool overflow = false;                                                /* the stack ran full: this lane finishes without the hierarchy */
-#endif
-    for (;;) {
+    /* One walk from the root with a stack of `capacity` entries behind store() / load(); true for a lane whose stack
+     * would have run over (a ray that passes all four boxes of node after node needs three entries per level): it has
+     * left the walk early and its best hit so far is a candidate like any other. */
+    auto walk = [&](auto store, auto load, int capacity) {
+        int cur = S.bvh_root, sp = 0;
+        bool overflow = false;
         for (;;) {
-            /* the node loop ends for the whole wavefront when no lane stands at a node, or when BDPT_BVH_WAIT lanes
-             * wait at leaves: they would otherwise idle through the others' node steps */
-            const bool at_node = cur >= 0;
-            if (__builtin_amdgcn_ballot_w64(at_node) == 0) break;
-            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT) break;
-            if (!at_node) continue;
+            for (;;) {
+                /* the node loop ends for the whole wavefront when no lane stands at a node, or when BDPT_BVH_WAIT lanes
+                 * wait at leaves: they would otherwise idle through the others' node steps */
+                const bool at_node = cur >= 0;
+                if (__builtin_amdgcn_ballot_w64(at_node) == 0) break;
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT) break;
+                if (!at_node) continue;
 #ifdef BDPT_BVH_STATS
-            stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
+                stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
 #endif
-            const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
+                const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
 #if BDPT_BVH_WIDE == 2
-            const float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
-            float t0, t1;
-            if (COUNT) *n_cull += 2;                                      /* box tests */
-            const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t0);
-            const bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t1);
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                const bool first0 = !(t1 < t0);
-                stack[sp * 64] = (uint32_t)(first0 ? c1 : c0);
-                sp++;
-                cur = first0 ? c0 : c1;
-            } else if (h0 || h1) {
-                cur = h0 ? c0 : c1;
-            } else if (sp == 0) {
-                cur = kDone;
-            } else {
-                sp--;
-                cur = (int)stack[sp * 64];
-            }
+                const float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3];
+                float t0, t1;
+                if (COUNT) *n_cull += 2;                                      /* box tests */
+                const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t0);
+                const bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t1);
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    const bool first0 = !(t1 < t0);
+                    store(sp, first0 ? c1 : c0); sp++;
+                    cur = first0 ? c0 : c1;
+                } else if (h0 || h1) {
+                    cur = h0 ? c0 : c1;
+                } else if (sp == 0) {
+                    cur = kDone;
+                } else {
+                    { sp--; cur = load(sp); }
+                }
 #else
-            const float4 lx = node[0], ly = node[1], lz = node[2], hx = node[3], hy = node[4], hz = node[5], rf = node[6];
-            if (COUNT) *n_cull += 4;                                      /* box tests */
-            float t0, t1, t2, t3;
-            const bool h0 = slab(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0), h1 = slab(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1);
-            const bool h2 = slab(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2), h3 = slab(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3);
-            /* the children this ray visits, nearest first: (entry parameter, reference) pairs through a sorting
-             * network; a child that is not visited (an empty slot's box is inside out: never hit) sorts last */
-            float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY, k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
-            int r0 = h0 ? __float_as_int(rf.x) : kDone, r1 = h1 ? __float_as_int(rf.y) : kDone, r2 = h2 ? __float_as_int(rf.z) : kDone,
-                r3 = h3 ? __float_as_int(rf.w) : kDone;
-            auto order = [](float &ka, int &ra, float &kb, int &rb) {
-                const bool swap = kb < ka;
-                const float k = swap ? kb : ka; kb = swap ? ka : kb; ka = k;
-                const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
-            };
-            order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
-            const int more = (r1 != kDone) + (r2 != kDone) + (r3 != kDone);
-            if (sp + more > S.bvh_stack_limit) { overflow = true; cur = kDone; break; }
-            if (r3 != kDone) { stack[sp * 64] = (uint32_t)r3; sp++; }
-            if (r2 != kDone) { stack[sp * 64] = (uint32_t)r2; sp++; }
-            if (r1 != kDone) { stack[sp * 64] = (uint32_t)r1; sp++; }
-            if (r0 != kDone) {
-                cur = r0;
-            } else if (sp == 0) {
-                cur = kDone;
-            } else {
-                sp--;
-                cur = (int)stack[sp * 64];
-            }
+                const float4 lx = node[0], ly = node[1], lz = node[2], hx = node[3], hy = node[4], hz = node[5], rf = node[6];
+                if (COUNT) *n_cull += 4;                                      /* box tests */
+                float t0, t1, t2, t3;
+                const bool h0 = slab(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0), h1 = slab(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1);
+                const bool h2 = slab(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2), h3 = slab(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3);
+                /* the children this ray visits, nearest first: (entry parameter, reference) pairs through a sorting
+                 * network; a child that is not visited (an empty slot's box is inside out: never hit) sorts last */
+                float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY, k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
+                int r0 = h0 ? __float_as_int(rf.x) : kDone, r1 = h1 ? __float_as_int(rf.y) : kDone, r2 = h2 ? __float_as_int(rf.z) : kDone,
+                    r3 = h3 ? __float_as_int(rf.w) : kDone;
+                auto order = [](float &ka, int &ra, float &kb, int &rb) {
+                    const bool swap = kb < ka;
+                    const float k = swap ? kb : ka; kb = swap ? ka : kb; ka = k;
+                    const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
+                };
+                order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
+                const int more = (r1 != kDone) + (r2 != kDone) + (r3 != kDone);
+                if (sp + more > capacity) { overflow = true; cur = kDone; break; }
+                if (r3 != kDone) { store(sp, r3); sp++; }
+                if (r2 != kDone) { store(sp, r2); sp++; }
+                if (r1 != kDone) { store(sp, r1); sp++; }
+                if (r0 != kDone) {
+                    cur = r0;
+                } else if (sp == 0) {
+                    cur = kDone;
+                } else {
+                    { sp--; cur = load(sp); }
+                }
 #endif
-        }
-        if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0) break;
-        if (cur < 0 && cur != kDone) {
+            }
+            if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0) break;
+            if (cur < 0 && cur != kDone) {
 #ifdef BDPT_BVH_STATS
-            stat[2]++; if (BDPT_BVH_FIRST_LANE) stat[3]++;
+                stat[2]++; if (BDPT_BVH_FIRST_LANE) stat[3]++;
 #endif
-            const uint32_t leaf = ~(uint32_t)cur;
-            const uint32_t first = leaf & 0x0FFFFFFFu, count = (leaf >> 28) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                const int i = (int)S.bvh_leaf_tri[first + k];
-                test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
+                const uint32_t leaf = ~(uint32_t)cur;
+                const uint32_t first = leaf & 0x0FFFFFFFu, count = (leaf >> 28) + 1u;
+                for (uint32_t k = 0; k < count; k++) {
+                    const int i = (int)S.bvh_leaf_tri[first + k];
+                    test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
+                }
+                if (COUNT) *n_exact += count;
+                reach = __builtin_sqrtf(b.d2) * per_length;
+                if (sp == 0) cur = kDone;
+                else { sp--; cur = load(sp); }
             }
-            if (COUNT) *n_exact += count;
-            reach = __builtin_sqrtf(b.d2) * per_length;
-            if (sp == 0) cur = kDone;
-            else { sp--; cur = (int)stack[sp * 64]; }
+        }
+        return overflow;
+    };
+    /* First with the stack in LDS (bvh_stack_limit entries: no more than the tree can need, no more than
+     * BDPT_BVH_STACK).  The lanes that ran over walk again, from the root, with BDPT_BVH_DEEP entries in their private
+     * memory (rays that graze a fine mesh do; on a soup of 100 000 triangles none does), and whoever runs over there
+     * too meets every triangle of the scene.  The comparison by (distance, index) makes a second meeting with a triangle
+     * harmless. */
+    bool overflow = walk([&](int at, int ref) { stack[at * 64] = (uint32_t)ref; }, [&](int at) { return (int)stack[at * 64]; }, S.bvh_stack_limit);
+    if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
+        asm volatile("");                                                  /* a real branch: the second walk is rare */
+        if (overflow) {
+            uint32_t deep[BDPT_BVH_DEEP];
+            overflow = walk([&](int at, int ref) { deep[at] = (uint32_t)ref; }, [&](int at) { return (int)deep[at]; }, S.bvh_stack_total);
         }
     }
-#if BDPT_BVH_WIDE == 4
-    /* a lane whose stack ran full (a ray that passes all four boxes of node after node: the bound is three entries
-     * per level) meets every triangle of the hierarchy instead; the comparison by (distance, index) makes a second
-     * meeting with a triangle harmless */
     if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
         for (int i = 0; i < S.n_triangles; i++) {
             const size_t r = (size_t)i * BDPT_TRI_F4;
@@ -707,7 +717,6 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
             if (overflow) test_triangle_unordered(b, rec, i, skip_t, o, d);
         }
     }
-#endif
 #ifdef BDPT_BVH_STATS
     for (int k = 0; k < 4; k++) BDPT_BVH_STAT(k, stat[k]);
     BDPT_BVH_STAT(4, 1);
@@ -766,7 +775,7 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
 #endif
     if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact);
     if (MODE == MODE_BVH)                                   /* the lane's column of its wavefront's stack, at the start of LDS */
-        return closest_hit_bvh<COUNT>(S, (uint32_t *)bdpt_lds + (threadIdx.x >> 6) * (BDPT_BVH_STACK * 64) + (threadIdx.x & 63), o, d, otype, oidx, &T.cull, &T.exact);
+        return closest_hit_bvh<COUNT>(S, (uint32_t *)bdpt_lds + (threadIdx.x >> 6) * (S.bvh_stack_limit * 64) + (threadIdx.x & 63), o, d, otype, oidx, &T.cull, &T.exact);
     return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
 }
 
@@ -1589,7 +1598,8 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
         if (K.scene.bvh_root != BDPT_BVH_NONE && (!K.scene.bvh_leaf_tri || (K.scene.bvh_root >= 0 && !K.scene.bvh_nodes))) return hipErrorInvalidValue;
         if (K.scene.bvh_n_brute > 0 && !K.scene.bvh_brute) return hipErrorInvalidValue;
         if (K.scene.bvh_stack_limit < 1 || K.scene.bvh_stack_limit > BDPT_BVH_STACK) return hipErrorInvalidValue;
-        lds = (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t);                 /* one wavefront per workgroup, its lanes' stacks */
+        if (K.scene.bvh_stack_total < K.scene.bvh_stack_limit || K.scene.bvh_stack_total > BDPT_BVH_DEEP) return hipErrorInvalidValue;
+        lds = (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t);        /* one wavefront per workgroup, its lanes' stacks */
     }
     dim3 grid;
     const dim3 block(K.block);
@@ -1723,7 +1733,7 @@ static void class_pool_shape(const bdpt_kargs &K, int variant, int &block, size_
     const size_t pool = (size_t)BDPT_CPOOL_WAVE_F4 * sizeof(float4);
     if (variant == BDPT_KERNEL_DIRECT || variant == BDPT_KERNEL_BVH) {
         block = 64;
-        lds = pool + (variant == BDPT_KERNEL_BVH ? (size_t)BDPT_BVH_STACK * 64 * sizeof(uint32_t) : 0);   /* the hierarchy walk's stacks come first */
+        lds = pool + (variant == BDPT_KERNEL_BVH ? (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t) : 0);   /* the hierarchy walk's stacks come first */
         return;
     }
     const size_t scene = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);

@@ -88,7 +88,8 @@ struct bdpt_dev_scene {
     const uint32_t *bvh_leaf_tri;   /* [triangles in the hierarchy] triangle indices in leaf order */
     const uint32_t *bvh_brute;  /* [bvh_n_brute] triangles every ray tests in full, ascending */
     int bvh_root, bvh_n_brute;
-    int bvh_stack_limit;        /* entries of the walk's per-lane stack a lane may use, at most BDPT_BVH_STACK */
+    int bvh_stack_limit;        /* entries of the walk's per-lane stack in LDS, at most BDPT_BVH_STACK */
+    int bvh_stack_total;        /* entries of the private-memory stack of a lane's second walk, at most BDPT_BVH_DEEP */
 };
 
 #define BDPT_INV_PRE_N 8

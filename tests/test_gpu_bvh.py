@@ -53,19 +53,23 @@ def test_equal_distances_go_to_the_lowest_index(bdpt, oracle):
     ctx.close()
 
 
-def test_a_walk_whose_stack_runs_over_finishes_without_the_hierarchy(bdpt, oracle, monkeypatch):
-    """A ray can pass all four boxes of node after node and need three stack entries per level.  With the stack limited
-    to two entries (BDPT_BVH_STACK_LIMIT, read when a context is created) most walks of this scene run over and meet
-    every triangle instead: the same bits."""
-    monkeypatch.setenv("BDPT_BVH_STACK_LIMIT", "2")
+@pytest.mark.parametrize("limit", ["2", "2,64", "3,7"])
+def test_a_walk_whose_stack_runs_over(bdpt, oracle, monkeypatch, limit):
+    """A ray can pass all four boxes of node after node and need three stack entries per level; a lane whose LDS stack
+    runs over walks again with a stack in its private memory, and if that runs over too it meets every triangle
+    instead.  BDPT_BVH_STACK_LIMIT (read when a context is created) makes the stacks small enough for that to happen
+    in nearly every search of this scene -- "2": both stacks two entries; "2,64": the second walk always succeeds;
+    "3,7": some of each -- and every bit stays."""
+    monkeypatch.setenv("BDPT_BVH_STACK_LIMIT", limit)
     rng = np.random.default_rng(21)
     scene = bvh_scenes.scene_for(bdpt, rng, "duplicates", 300)
     W, H = 40, 30
     ctx, st, p = _pair(bdpt, oracle, scene, W, H, seed=3, kernel_variant=bdpt.KERNEL_BVH)
+    assert ctx.hierarchy_info()["stack_entries"] == int(limit.split(",")[0])
     ctx.render(4)
     assert ctx.last_launch_variant() == bdpt.KERNEL_BVH
     oracle.render(st, scene, scene.camera, p, 4, n_threads=8)
-    _compare(bdpt, ctx, st, "stack of two entries:")
+    _compare(bdpt, ctx, st, "stack limit %s:" % limit)
     ctx.close()
 
 
@@ -85,3 +89,18 @@ def test_connected_mesh_with_shared_edges(bdpt, oracle, flat):
             _compare(bdpt, ctx, st, "mesh flat=%s variant %d launch %d:" % (flat, variant, s))
         assert (st.eye_hit[..., 1][st.eye_hit[..., 0] == 2] >= 12).any()         # the mesh is in view
         ctx.close()
+
+
+def test_hierarchy_info_and_reserved_stack(bdpt):
+    """What the builder says about its tree: a walk pushes at most three entries per level of four-wide nodes, the
+    context reserves that many per lane (never more than 48), the oversized walls of the box stay outside, and a scene
+    without triangles has an empty hierarchy."""
+    with bdpt.Context(32, 32) as ctx:
+        assert ctx.hierarchy_info() is None                                   # no scene yet
+        ctx.upload_scene(bdpt.Scene.soup(5000))
+        info = ctx.hierarchy_info()
+        assert info["outside"] == 12 and 5000 // 4 < info["nodes"] < 5000
+        assert info["depth"] == 13                                            # ceil(log2(5000)): median splits down to one triangle
+        assert 7 <= info["stack_entries"] <= 3 * ((info["depth"] + 1) // 2) + 3
+        ctx.upload_scene(bdpt.Scene.outdoor())
+        assert ctx.hierarchy_info() == dict(nodes=0, depth=0, stack_entries=1, outside=0)

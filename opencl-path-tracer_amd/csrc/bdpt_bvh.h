@@ -27,8 +27,10 @@
  * few that are far larger than the rest (the walls of a room around a soup of small triangles: their boxes would
  * swallow every node above them) are kept out of the hierarchy in a short list that every ray tests in full.
  *
- * Built by median split of the longest axis of the centres' bounds (depth ceil(log2(n / leaf size)) + 1 whatever
- * the scene looks like), then folded into nodes of four children.  A walk pushes up to three entries per level on its
+ * Built top down: a set of triangles is cut where the surface-area heuristic over 16 bins of each axis is least
+ * (boxes' areas times triangle counts), provided neither side gets less than an eighth -- else at the median of the
+ * longest axis of the centres' bounds -- so the depth stays logarithmic whatever the scene looks like; the binary tree
+ * is then folded into nodes of four children.  A walk pushes up to three entries per level on its
  * per-lane stack; the builder reports the most a walk of this tree can need (stack_need), a launch reserves that much
  * LDS per lane, up to BDPT_BVH_STACK entries; a lane whose stack would run over walks again with BDPT_BVH_DEEP entries
  * in its private memory, and if that is not enough either it meets every triangle instead (bdpt_kernels.hip), so any
@@ -50,6 +52,9 @@
 #define BDPT_BVH_EMPTY ((int)0x80000000)   /* reference of a child slot that holds nothing (its box is inside out); no leaf has this value */
 #ifndef BDPT_BVH_LEAF_MAX
 #define BDPT_BVH_LEAF_MAX 1       /* triangles per leaf */
+#endif
+#ifndef BDPT_BVH_SAH
+#define BDPT_BVH_SAH 16           /* bins per axis of the builder's surface-area split; 0 = median splits only */
 #endif
 #ifndef BDPT_BVH_WAIT
 #define BDPT_BVH_WAIT 4           /* lanes waiting at leaves that end the walk's node loop for their wavefront */
@@ -131,7 +136,7 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
         std::vector<uint32_t> &idx;
         bdpt_bvh_host &out;
         std::vector<Pair> &pairs;
-        Ref build(size_t first, size_t last)
+        Ref build(size_t first, size_t last, int level = 0)
         {
             Ref r;
             for (int k = 0; k < 3; k++) { r.b.lo[k] = INFINITY; r.b.hi[k] = -INFINITY; }
@@ -156,15 +161,75 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
             }
             int axis = 0;
             for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-            const size_t mid = first + count / 2;
-            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + last, [&](uint32_t a, uint32_t b) {
-                const float ca = axis == 0 ? bound[a].x : axis == 1 ? bound[a].y : bound[a].z;
-                const float cb = axis == 0 ? bound[b].x : axis == 1 ? bound[b].y : bound[b].z;
-                return ca < cb || (ca == cb && a < b);
-            });
+            size_t mid = first + count / 2;
+            auto centre = [&](uint32_t t) { return axis == 0 ? bound[t].x : axis == 1 ? bound[t].y : bound[t].z; };
+            bool split = false;
+#if BDPT_BVH_SAH > 0
+            /* surface-area heuristic over BDPT_BVH_SAH bins of each axis: the cut that minimises the boxes' areas times
+             * their triangle counts; taken when neither side gets less than an eighth (depth stays logarithmic), else
+             * the median of the longest axis below */
+            if (count > 8 && level < 64) {
+                constexpr int NB = BDPT_BVH_SAH;
+                auto area = [](const Box &x) {
+                    const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
+                    return dx * dy + dy * dz + dz * dx;
+                };
+                double best = INFINITY;
+                int cut = -1, cut_axis = -1;
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!(chi[ax] > clo[ax])) continue;
+                    Box bb[NB];
+                    size_t bn[NB];
+                    for (int q = 0; q < NB; q++) { bn[q] = 0; for (int k = 0; k < 3; k++) { bb[q].lo[k] = INFINITY; bb[q].hi[k] = -INFINITY; } }
+                    const double scale = NB / ((double)chi[ax] - clo[ax]);
+                    for (size_t j = first; j < last; j++) {
+                        const uint32_t t = idx[j];
+                        const float c = ax == 0 ? bound[t].x : ax == 1 ? bound[t].y : bound[t].z;
+                        const int q = std::min(NB - 1, std::max(0, (int)((c - clo[ax]) * scale)));
+                        bn[q]++;
+                        for (int k = 0; k < 3; k++) { bb[q].lo[k] = std::min(bb[q].lo[k], box[t].lo[k]); bb[q].hi[k] = std::max(bb[q].hi[k], box[t].hi[k]); }
+                    }
+                    double right_area[NB];
+                    size_t right_n[NB];
+                    Box acc;
+                    for (int k = 0; k < 3; k++) { acc.lo[k] = INFINITY; acc.hi[k] = -INFINITY; }
+                    size_t n = 0;
+                    for (int q = NB - 1; q > 0; q--) {
+                        n += bn[q];
+                        for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], bb[q].lo[k]); acc.hi[k] = std::max(acc.hi[k], bb[q].hi[k]); }
+                        right_area[q] = n ? area(acc) : 0.0;
+                        right_n[q] = n;
+                    }
+                    for (int k = 0; k < 3; k++) { acc.lo[k] = INFINITY; acc.hi[k] = -INFINITY; }
+                    n = 0;
+                    for (int q = 0; q + 1 < NB; q++) {
+                        n += bn[q];
+                        for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], bb[q].lo[k]); acc.hi[k] = std::max(acc.hi[k], bb[q].hi[k]); }
+                        if (n < count / 8 || right_n[q + 1] < count / 8) continue;
+                        const double cost = area(acc) * (double)n + right_area[q + 1] * (double)right_n[q + 1];
+                        if (cost < best) { best = cost; cut = q; cut_axis = ax; }
+                    }
+                }
+                if (cut >= 0) {
+                    const double scale = NB / ((double)chi[cut_axis] - clo[cut_axis]);
+                    const auto m = std::partition(idx.begin() + first, idx.begin() + last, [&](uint32_t t) {
+                        const float c = cut_axis == 0 ? bound[t].x : cut_axis == 1 ? bound[t].y : bound[t].z;
+                        return std::min(NB - 1, std::max(0, (int)((c - clo[cut_axis]) * scale))) <= cut;
+                    });
+                    mid = (size_t)(m - idx.begin());
+                    split = mid > first && mid < last;
+                    if (!split) mid = first + count / 2;
+                }
+            }
+#endif
+            if (!split)
+                std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + last, [&](uint32_t a, uint32_t b) {
+                    const float ca = centre(a), cb = centre(b);
+                    return ca < cb || (ca == cb && a < b);
+                });
             const size_t node = pairs.size();
             pairs.emplace_back();
-            const Ref a = build(first, mid), b = build(mid, last);
+            const Ref a = build(first, mid, level + 1), b = build(mid, last, level + 1);
             pairs[node].b[0] = a.b; pairs[node].b[1] = b.b;
             pairs[node].ref[0] = a.ref; pairs[node].ref[1] = b.ref;
             for (int k = 0; k < 3; k++) { r.b.lo[k] = std::min(a.b.lo[k], b.b.lo[k]); r.b.hi[k] = std::max(a.b.hi[k], b.b.hi[k]); }

@@ -100,7 +100,7 @@ def test_hierarchy_info_and_reserved_stack(bdpt):
         ctx.upload_scene(bdpt.Scene.soup(5000))
         info = ctx.hierarchy_info()
         assert info["outside"] == 12 and 5000 // 4 < info["nodes"] < 5000
-        assert info["depth"] == 13                                            # ceil(log2(5000)): median splits down to one triangle
+        assert 13 <= info["depth"] <= 39                                      # between ceil(log2(5000)) and cuts that leave an eighth on one side
         assert 7 <= info["stack_entries"] <= 3 * ((info["depth"] + 1) // 2) + 3
         ctx.upload_scene(bdpt.Scene.outdoor())
         assert ctx.hierarchy_info() == dict(nodes=0, depth=0, stack_entries=1, outside=0)

@@ -56,6 +56,9 @@
 #ifndef BDPT_BVH_SAH
 #define BDPT_BVH_SAH 16           /* bins per axis of the builder's surface-area split; 0 = median splits only */
 #endif
+#ifndef BDPT_BVH_SAH_SHARE
+#define BDPT_BVH_SAH_SHARE 8      /* a surface-area cut leaves each side at least one part in this many */
+#endif
 #ifndef BDPT_BVH_WAIT
 #define BDPT_BVH_WAIT 4           /* lanes waiting at leaves that end the walk's node loop for their wavefront */
 #endif
@@ -205,7 +208,7 @@ inline bool bdpt_bvh_build(Vertex vertex, const float4 *bound, const double *big
                     for (int q = 0; q + 1 < NB; q++) {
                         n += bn[q];
                         for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], bb[q].lo[k]); acc.hi[k] = std::max(acc.hi[k], bb[q].hi[k]); }
-                        if (n < count / 8 || right_n[q + 1] < count / 8) continue;
+                        if (n < count / BDPT_BVH_SAH_SHARE || right_n[q + 1] < count / BDPT_BVH_SAH_SHARE) continue;
                         const double cost = area(acc) * (double)n + right_area[q + 1] * (double)right_n[q + 1];
                         if (cost < best) { best = cost; cut = q; cut_axis = ax; }
                     }

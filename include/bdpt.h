@@ -131,7 +131,7 @@ enum { BDPT_INTEGRATOR_BIDIRECTIONAL = 0, BDPT_INTEGRATOR_PATH_TRACE = 1 };
  *         instead of all of them.  The reference's in-order walk keeps the nearest hit and among
  *         equally near ones the lowest index; the walk keeps exactly that one (any scene size;
  *         refused for scenes with more than 1024 triangles too thin for a bounding sphere).
- * AUTO:   BVH (TILED if the scene cannot have a hierarchy) when the scene does not fit LDS2 or
+ * AUTO:   BVH (TILED for fewer than 512 triangles or if the scene cannot have a hierarchy) when the scene does not fit LDS2 or
  *         when enough of its triangles are small against the scene for the bounding spheres to
  *         pay (estimated at upload), else LDS2 (LDS for a scene without triangles). */
 enum { BDPT_KERNEL_AUTO = 0, BDPT_KERNEL_DIRECT = 1, /* 2: a variant that was removed */ BDPT_KERNEL_LDS = 3, BDPT_KERNEL_TILED = 4, BDPT_KERNEL_LDS2 = 5, BDPT_KERNEL_BVH = 6 };

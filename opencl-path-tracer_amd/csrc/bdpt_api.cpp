@@ -116,6 +116,11 @@ struct bdpt_ctx {
 #ifndef BDPT_POOL_AUTO_CHUNK_MIN_SPP
 #define BDPT_POOL_AUTO_CHUNK_MIN_SPP 128
 #endif
+/* AUTO walks the hierarchy from this many triangles on; below, meeting every bounding sphere is faster (soups of 150 / 300 /
+ * 1000 / 3000 triangles in the Cornell box, 64 samples at 1080p: exhaustive 39 / 54 / 129 / 344 ms, hierarchy 55 / 66 / 95 / 140) */
+#ifndef BDPT_BVH_AUTO_MIN_TRIANGLES
+#define BDPT_BVH_AUTO_MIN_TRIANGLES 512
+#endif
 /* launches in index order sort a wavefront's pixels by the length of their next sample (bdpt_class_pool.h) from this
  * many samples per pixel on, unless the caller chose (bdpt_set_path_scheduling) */
 #ifndef BDPT_CPOOL_AUTO_MIN_SPP
@@ -972,10 +977,11 @@ int bdpt_render_async(bdpt_ctx *ctx, int spp)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: scene does not fit the LDS-resident kernel");
     if (variant == BDPT_KERNEL_BVH && !ctx->have_bvh)
         return fail(ctx, BDPT_ERR_INVALID, "bdpt_render: the scene has no triangle hierarchy (too many triangles that no sphere bounds, or too deep for the walk's stack)");
-    /* AUTO: see the estimate in bdpt_upload_scene; scenes for the many-triangle kernels walk the hierarchy when they have one */
+    /* AUTO: see the estimate in bdpt_upload_scene; scenes for the many-triangle kernels walk the hierarchy when they have
+     * one and enough triangles for it to pay */
     if (variant == BDPT_KERNEL_AUTO)
         variant = !(bdpt_lds_scene_bytes(K.scene, true) <= BDPT_LDS_SCENE_MAX && K.scene.n_triangles <= BDPT_CULL_MAX_TRIANGLES && !ctx->auto_tiled)
-                      ? (ctx->have_bvh ? BDPT_KERNEL_BVH : BDPT_KERNEL_TILED)
+                      ? (ctx->have_bvh && K.scene.n_triangles >= BDPT_BVH_AUTO_MIN_TRIANGLES ? BDPT_KERNEL_BVH : BDPT_KERNEL_TILED)
                   : K.scene.n_triangles > 0 ? BDPT_KERNEL_LDS2 : BDPT_KERNEL_LDS;    /* nothing for the two-stage test to do without triangles */
     /* Pixels sorted by the class of their next sample (bdpt_class_pool.h): launches in index order.  Left to itself the
      * library runs them so from BDPT_CPOOL_AUTO_MIN_SPP samples on (1080p Cornell box, sequential generator, running

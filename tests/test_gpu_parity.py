@@ -551,7 +551,7 @@ def test_auto_picks_the_kernel_by_the_shape_of_the_scene(bdpt):
     assert variant_for(bdpt.Scene.cornell_planes()) == bdpt.KERNEL_LDS     # no triangles: nothing for two stages to do
     assert variant_for(bdpt.Scene.outdoor()) == bdpt.KERNEL_LDS
     assert variant_for(bdpt.Scene.soup(8)) == bdpt.KERNEL_LDS2
-    assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_BVH
+    assert variant_for(bdpt.Scene.soup(40)) == bdpt.KERNEL_TILED            # too few triangles for a hierarchy to pay
     assert variant_for(bdpt.Scene.soup(2000)) == bdpt.KERNEL_BVH
 
 

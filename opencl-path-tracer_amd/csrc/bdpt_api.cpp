@@ -68,7 +68,8 @@ struct bdpt_ctx {
     int bvh_root = BDPT_BVH_NONE, bvh_n_brute = 0, bvh_depth = 0, bvh_nodes = 0;
     int bvh_stack_limit = 1;            /* entries of the walk's stack a launch reserves in LDS per lane: what the tree can need, at most BDPT_BVH_STACK */
     int bvh_stack_total = 1;            /* entries of the private-memory stack of a lane's second walk */
-    int bvh_lds_cap = BDPT_BVH_STACK, bvh_stack_cap = BDPT_BVH_DEEP;   /* BDPT_BVH_STACK_LIMIT in the environment lowers it (testing aid) */
+    int bvh_lds_cap = BDPT_BVH_STACK, bvh_stack_cap = BDPT_BVH_DEEP;
+    int bvh_share_min = BDPT_BVH_SHARE_MIN_TRIANGLES;    /* BDPT_BVH_SHARE_MIN in the environment changes it (testing aid) */   /* BDPT_BVH_STACK_LIMIT in the environment lowers it (testing aid) */
     bool have_bvh = false;              /* false: the scene cannot have one (bdpt_bvh_build), BDPT_KERNEL_BVH is refused */
     uint32_t *d_seed_w = nullptr;
     float4 *d_accum_own = nullptr;
@@ -254,6 +255,12 @@ int bdpt_create(int device_ordinal, int width, int height, bdpt_ctx **out)
         const long a = std::strtol(env, &end, 10);
         const long b = end && *end == ',' ? std::strtol(end + 1, nullptr, 10) : a;
         if (a >= 1 && a <= BDPT_BVH_STACK && b >= a && b <= BDPT_BVH_DEEP) { ctx->bvh_lds_cap = (int)a; ctx->bvh_stack_cap = (int)b; }
+    }
+    /* BDPT_BVH_SHARE_MIN=n in the environment, for every context: hierarchies of n triangles or more are walked with the
+     * lanes of a wavefront sharing work (default 8192; a testing aid: 0 shares always, a large number never) */
+    if (const char *env = std::getenv("BDPT_BVH_SHARE_MIN")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 0 && v <= 0x7FFFFFFF) ctx->bvh_share_min = (int)v;
     }
     const size_t npix = (size_t)width * height;
     auto bail = [&](hipError_t err, const char *what) {
@@ -865,6 +872,7 @@ static int fill_kargs(bdpt_ctx *ctx, int spp, bdpt_kargs &K)
     K.scene.tri = ctx->d_tri; K.scene.tri_bound = ctx->d_tri_bound; K.scene.tri_cull = ctx->d_tri_cull; K.scene.cull_f4 = ctx->cull_f4; K.scene.cull_c = ctx->cull_c; std::memcpy(K.scene.cull_group, ctx->cull_group, sizeof K.scene.cull_group); K.scene.tri_surf = ctx->d_tri_surf;
     K.scene.bvh_nodes = ctx->d_bvh_nodes; K.scene.bvh_leaf_tri = ctx->d_bvh_leaf_tri; K.scene.bvh_brute = ctx->d_bvh_brute;
     K.scene.bvh_root = ctx->bvh_root; K.scene.bvh_n_brute = ctx->bvh_n_brute; K.scene.bvh_stack_limit = ctx->bvh_stack_limit; K.scene.bvh_stack_total = ctx->bvh_stack_total;
+    K.scene.bvh_share = ctx->n_triangles - ctx->bvh_n_brute >= ctx->bvh_share_min ? 1 : 0;
     K.scene.surf = ctx->d_surf;
     K.scene.n_spheres = (int)ctx->spheres.size();
     K.scene.n_planes = ctx->n_planes;

@@ -60,10 +60,14 @@
 #define BDPT_BVH_SAH_SHARE 8      /* a surface-area cut leaves each side at least one part in this many */
 #endif
 #ifndef BDPT_BVH_WAIT
-#define BDPT_BVH_WAIT 4           /* lanes waiting at leaves that end the walk's node loop for their wavefront */
+#define BDPT_BVH_WAIT 8           /* lanes waiting at leaves that end the walk's node loop for their wavefront, when lanes share work */
 #endif
+#ifndef BDPT_BVH_WAIT_ALONE
+#define BDPT_BVH_WAIT_ALONE 4     /* the same when every lane walks for itself (leaf phases are cheaper there) */
+#endif
+#define BDPT_BVH_SHARE_MIN_TRIANGLES 8192   /* scenes from this size on are walked with the lanes of a wavefront sharing work */
 #ifndef BDPT_BVH_STACK
-#define BDPT_BVH_STACK 24         /* entries of the walk's per-lane stack in LDS, at most (a launch reserves what its tree can need) */
+#define BDPT_BVH_STACK 22         /* entries of the walk's per-lane stack in LDS, at most (a launch reserves what its tree can need) */
 #endif
 #define BDPT_BVH_DEEP 64          /* entries of the stack in a lane's private memory, for the second walk of a lane that ran over */
 #define BDPT_BVH_BRUTE_MAX 1024   /* triangles outside the hierarchy, at most */

@@ -61,7 +61,7 @@ void bdpt_class_pool_kernel(const bdpt_kargs K)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = K.block >> 6;
     /* behind the scene and the lanes' parked eye vertices (lane_park), or behind the stacks of the hierarchy walk */
     const LdsLayout L = MODE == MODE_LDS2 ? lds_layout<true>(S) : lds_layout<false>(S);
-    const int base_f4 = MODE == MODE_DIRECT ? 0 : MODE == MODE_BVH ? (int)(blockDim.x >> 6) * (S.bvh_stack_limit * 64 / 4)     /* behind the walk's stacks */
+    const int base_f4 = MODE == MODE_DIRECT ? 0 : MODE == MODE_BVH ? (int)(blockDim.x >> 6) * (S.bvh_stack_limit * 64 / 4 + BDPT_BVH_SHARE_BYTES / 16)     /* behind the walk's stacks */
                                                 : L.ids + L.n_ids / 4 + (int)blockDim.x * BDPT_PARK_F4;
     uint32_t *const words = (uint32_t *)(bdpt_lds + base_f4 + wv * BDPT_CPOOL_WAVE_F4);      /* [64][BDPT_CPOOL_LANE_WORDS] */
     uint32_t *const list = words + (64 * BDPT_CPOOL_LANE_WORDS + 3) / 4 * 4;

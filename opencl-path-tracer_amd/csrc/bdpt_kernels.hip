@@ -543,6 +543,41 @@ BDPT_DEV void test_triangle_unordered(Best &b, const float4 *rec, int i, int ski
     if (i != skip) best_consider_unordered(b, p, o, i);                              /* :436, :441-448 */
 }
 
+#ifndef BDPT_BVH_STEAL
+#define BDPT_BVH_STEAL 1          /* the lanes of a wavefront share the work of their walks (closest_hit_bvh) */
+#endif
+#ifndef BDPT_BVH_STEAL_MIN
+#define BDPT_BVH_STEAL_MIN 8      /* idle lanes it takes for a round of sharing */
+#endif
+/* bytes of LDS behind a wavefront's stacks when its lanes share work: 64 words of 8 bytes and one more */
+#define BDPT_BVH_SHARE_BYTES (BDPT_BVH_STEAL ? 64 * 8 + 64 : 0)
+
+/* the reference's triangle test (kernel0.cl:273-312) as test_triangle_unordered runs it, up to the accepted point:
+ * true and distance(p, o) as the search compares it (:441) when the ray hits */
+BDPT_DEV bool triangle_hit_distance(const float4 *rec, clm_f3 o, clm_f3 d, float &dist)
+{
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    const float e2z = rec[5].x;
+    clm_f3 n = clm_make3(q0.x, q0.y, q0.z);
+    float val = clm_dot3(d, n);                                                      /* :286 */
+    clm_f3 a = clm_make3(q0.w, q1.x, q1.y);
+    float t = clm_div(clm_dot3(clm_sub3(a, o), n), val);                             /* :291 */
+    if (val > 0 || t < 0) return false;                                              /* :288, :292 */
+    clm_f3 p = clm_mad3(t, d, o);                                                    /* :295 */
+    clm_f3 e0 = clm_make3(q1.z, q1.w, q2.x);
+    clm_f3 c = clm_make3(q2.y, q2.z, q2.w);
+    clm_f3 e1 = clm_make3(q3.x, q3.y, q3.z);
+    clm_f3 bb = clm_make3(q3.w, q4.x, q4.y);
+    clm_f3 e2 = clm_make3(q4.z, q4.w, e2z);
+    float dA = clm_dot3(clm_cross3(clm_sub3(p, a), e0), n);                          /* :298 */
+    float dB = clm_dot3(clm_cross3(clm_sub3(p, c), e1), n);                          /* :299 */
+    float dC = clm_dot3(clm_cross3(clm_sub3(p, bb), e2), n);                         /* :300 */
+    if (dA < 0 || dB < 0 || dC < 0) return false;                                    /* :304 */
+    const clm_f3 v = clm_sub3(p, o);
+    dist = clm_sqrt(clm_dot3(v, v));
+    return true;
+}
+
 /* -DBDPT_BVH_STATS (tools/bvh_stats.py): how well the lanes of a wavefront keep together in the walk.  Sums over all
  * searches of a launch: node steps of the lanes / trips of the wavefronts through the node loop / leaves of the lanes /
  * trips through the leaf block / searches of the lanes / searches of the wavefronts. */
@@ -576,14 +611,21 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
     }
     if (S.bvh_root == BDPT_BVH_NONE) return finish_hit(S, b, d);
 
-    const float dd = clm_dot3(d, d), oo = clm_dot3(o, o);
-    const bool all = !(oo < 1.0e30f) || !(dd > 1.0e-30f && dd < 1.0e30f);  /* no box test for this ray (a NaN lands here too) */
-    /* the boxes' widening for this ray */
-    const float q = 2.0e-5f * (1.0f + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
-    const clm_f3 op = clm_make3(o.x + q, o.y + q, o.z + q), om = clm_make3(o.x - q, o.y - q, o.z - q);
-    auto inverse = [](float x) { return 1.0f / (fabsf(x) < 1.0e-30f ? __builtin_copysignf(1.0e-30f, x) : x); };
-    const clm_f3 inv = clm_make3(inverse(d.x), inverse(d.y), inverse(d.z));
-    const float per_length = 1.0001f / __builtin_sqrtf(dd);               /* ray parameter per unit of distance, rounded up */
+    /* what the box tests need of a ray (its own, or -- when lanes share work, below -- another lane's) */
+    bool all;                                                             /* no box test for this ray (a NaN lands here too) */
+    clm_f3 op, om, inv;                                                   /* origin plus and minus the boxes' widening for this ray; 1 / direction */
+    float per_length;                                                     /* ray parameter per unit of distance, rounded up */
+    auto ray_numbers = [&](clm_f3 ro, clm_f3 rd) {
+        const float dd = clm_dot3(rd, rd), oo = clm_dot3(ro, ro);
+        all = !(oo < 1.0e30f) || !(dd > 1.0e-30f && dd < 1.0e30f);
+        const float q = 2.0e-5f * (1.0f + fabsf(ro.x) + fabsf(ro.y) + fabsf(ro.z));
+        op = clm_make3(ro.x + q, ro.y + q, ro.z + q);
+        om = clm_make3(ro.x - q, ro.y - q, ro.z - q);
+        auto inverse = [](float x) { return 1.0f / (fabsf(x) < 1.0e-30f ? __builtin_copysignf(1.0e-30f, x) : x); };
+        inv = clm_make3(inverse(rd.x), inverse(rd.y), inverse(rd.z));
+        per_length = 1.0001f / __builtin_sqrtf(dd);
+    };
+    ray_numbers(o, d);
     float reach = __builtin_sqrtf(b.d2) * per_length;                     /* no hit beyond this parameter can win */
     /* the ray's line against one box: does it pass, and where does it enter */
     auto slab = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, float &enter) {
@@ -622,7 +664,7 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
                  * wait at leaves: they would otherwise idle through the others' node steps */
                 const bool at_node = cur >= 0;
                 if (__builtin_amdgcn_ballot_w64(at_node) == 0) break;
-                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT) break;
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT_ALONE) break;
                 if (!at_node) continue;
 #ifdef BDPT_BVH_STATS
                 stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
@@ -696,12 +738,151 @@ BDPT_DEV Hit closest_hit_bvh(const bdpt_dev_scene &S, uint32_t *stack, clm_f3 o,
         }
         return overflow;
     };
+#if BDPT_BVH_STEAL
+    /*
+     * The first walk with the lanes of the wavefront sharing work.  The rays of a wavefront are unrelated and a search
+     * lasts as long as its longest walk, with most lanes idle for most of it; so a lane whose walk has ended takes a
+     * subtree off the bottom of another lane's stack -- the farthest, largest one that lane has waiting -- and walks it
+     * for that lane's ray.  What a lane finds for a ray, its own included, goes to the ray owner's word of LDS: the
+     * least (distance, index) of all hits, kept by a 64-bit atomic minimum of the distance's bits over the triangle's
+     * index (distances are not negative, so their bits order as they do).  That word also bounds the walks of
+     * everybody working for the ray.  When no lane has a node, a leaf or anything to give, every owner runs the
+     * reference's test once more on its word's triangle: the comparison with the spheres, planes and listed triangles
+     * met before, and the hit point.  Lanes that were not part of the search when it began take no part.
+     */
+    auto walk_shared = [&]() {
+        const int lane = threadIdx.x & 63;
+        uint32_t *const wave_lds = stack - lane;
+        unsigned long long *const found = (unsigned long long *)(wave_lds + S.bvh_stack_limit * 64);    /* [64] best (distance, index) per owner */
+        unsigned long long *const ran_over = found + 64;                                               /* one bit per owner */
+        constexpr unsigned long long kNothing = ~0ull;
+        found[lane] = kNothing;
+        __hip_atomic_fetch_and(ran_over, ~(1ull << lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int owner = lane;                                                 /* the lane whose ray this lane works for; op, om, inv, all, reach are that ray's */
+        int cur = S.bvh_root, sp = 0, lo = 0;                             /* this lane's stack holds [lo, sp) */
+        auto pop = [&]() {
+            if (sp == lo) cur = kDone;
+            else { sp--; cur = (int)stack[sp * 64]; }
+        };
+        for (;;) {
+            for (;;) {
+                const bool at_node = cur >= 0;
+                if (__builtin_amdgcn_ballot_w64(at_node) == 0) break;
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= BDPT_BVH_WAIT) break;
+                if (!at_node) continue;
+#ifdef BDPT_BVH_STATS
+                stat[0]++; if (BDPT_BVH_FIRST_LANE) stat[1]++;
+#endif
+                const float4 *node = S.bvh_nodes + (size_t)cur * BDPT_BVH_NODE_F4;
+                const float4 lx = node[0], ly = node[1], lz = node[2], hx = node[3], hy = node[4], hz = node[5], rf = node[6];
+                if (COUNT) *n_cull += 4;
+                float t0, t1, t2, t3;
+                const bool h0 = slab(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0), h1 = slab(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1);
+                const bool h2 = slab(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2), h3 = slab(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3);
+                float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY, k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
+                int r0 = h0 ? __float_as_int(rf.x) : kDone, r1 = h1 ? __float_as_int(rf.y) : kDone, r2 = h2 ? __float_as_int(rf.z) : kDone,
+                    r3 = h3 ? __float_as_int(rf.w) : kDone;
+                auto order = [](float &ka, int &ra, float &kb, int &rb) {
+                    const bool swap = kb < ka;
+                    const float k = swap ? kb : ka; kb = swap ? ka : kb; ka = k;
+                    const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
+                };
+                order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
+                const int more = (r1 != kDone) + (r2 != kDone) + (r3 != kDone);
+                if (sp + more > S.bvh_stack_limit) {                      /* the owner walks again by itself, afterwards */
+                    __hip_atomic_fetch_or(ran_over, 1ull << owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    sp = lo;
+                    cur = kDone;
+                    continue;
+                }
+                if (r3 != kDone) { stack[sp * 64] = (uint32_t)r3; sp++; }
+                if (r2 != kDone) { stack[sp * 64] = (uint32_t)r2; sp++; }
+                if (r1 != kDone) { stack[sp * 64] = (uint32_t)r1; sp++; }
+                if (r0 != kDone) cur = r0;
+                else pop();
+            }
+            /* the triangle tests want the ray itself: fetched from its owner's registers by every lane, here where all
+             * lanes of the search still run together (a lane that is switched off has nothing to give) */
+            auto own = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)__float_as_uint(v))); };
+            const clm_f3 jo = clm_make3(own(o.x), own(o.y), own(o.z)), jd = clm_make3(own(d.x), own(d.y), own(d.z));
+            const int jskip = __builtin_amdgcn_ds_bpermute(owner << 2, skip_t);
+            if (cur < 0 && cur != kDone) {
+#ifdef BDPT_BVH_STATS
+                stat[2]++; if (BDPT_BVH_FIRST_LANE) stat[3]++;
+#endif
+                const uint32_t leaf = ~(uint32_t)cur;
+                const uint32_t first = leaf & 0x0FFFFFFFu, count = (leaf >> 28) + 1u;
+                for (uint32_t k = 0; k < count; k++) {
+                    const int i = (int)S.bvh_leaf_tri[first + k];
+                    float dist;
+                    if (triangle_hit_distance(S.tri + (size_t)i * BDPT_TRI_F4, jo, jd, dist) && i != jskip)
+                        __hip_atomic_fetch_min(&found[owner], ((unsigned long long)__float_as_uint(dist) << 32) | (uint32_t)i,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (COUNT) *n_exact += count;
+                /* whatever anybody has found for this ray bounds the rest of this walk */
+                reach = __builtin_fminf(reach, __uint_as_float((uint32_t)(found[owner] >> 32) & 0x7FFFFFFFu) * per_length);
+                pop();
+            }
+            /* ---- lanes without work take some from lanes that have it waiting ---- */
+            const bool idle = cur == kDone, giving = !idle && sp - lo >= 1;
+            const unsigned long long idle_m = __builtin_amdgcn_ballot_w64(idle), giving_m = __builtin_amdgcn_ballot_w64(giving);
+            if (__builtin_amdgcn_ballot_w64(!idle) == 0) break;           /* nobody has anything left */
+            if (giving_m != 0 && __builtin_popcountll(idle_m) >= BDPT_BVH_STEAL_MIN) {
+                const int pairs = min(__builtin_popcountll(idle_m), __builtin_popcountll(giving_m));
+                auto rank_in = [&](unsigned long long m) {
+                    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                };
+                const bool taking = idle && rank_in(idle_m) < pairs;
+                const bool robbed = giving && rank_in(giving_m) < pairs;
+                /* the lane this lane takes from: the giving lane of its own rank */
+                int from = 0, r = rank_in(idle_m);
+#pragma unroll
+                for (int w = 32; w >= 1; w >>= 1) {
+                    const int c = __builtin_popcountll((giving_m >> from) & ((1ull << w) - 1ull));
+                    const bool up = r >= c;
+                    r -= up ? c : 0;
+                    from += up ? w : 0;
+                }
+                from = taking ? from : lane;
+                auto pull = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)__float_as_uint(v))); };
+                auto pull_i = [&](int v) { return __builtin_amdgcn_ds_bpermute(from << 2, v); };
+                const clm_f3 nop = clm_make3(pull(op.x), pull(op.y), pull(op.z)), nom = clm_make3(pull(om.x), pull(om.y), pull(om.z)),
+                             ninv = clm_make3(pull(inv.x), pull(inv.y), pull(inv.z));
+                const float nreach = pull(reach), nper = pull(per_length);
+                const int nowner = pull_i(owner), nlo = pull_i(lo), nall = pull_i(all ? 1 : 0);
+                if (taking) {
+                    op = nop; om = nom; inv = ninv; reach = nreach; per_length = nper; all = nall != 0; owner = nowner;
+                    cur = (int)wave_lds[nlo * 64 + from];
+                    sp = lo = 0;
+                }
+                if (robbed) lo++;
+            }
+        }
+        /* every owner: its ray's best triangle against what it had before, and whether somebody's stack ran over */
+        ray_numbers(o, d);
+        const unsigned long long mine = found[lane];
+        if (mine != kNothing) {
+            const int i = (int)(uint32_t)mine;
+            test_triangle_unordered(b, S.tri + (size_t)i * BDPT_TRI_F4, i, skip_t, o, d);
+        }
+        reach = __builtin_sqrtf(b.d2) * per_length;
+        return ((*ran_over >> lane) & 1ull) != 0ull;
+    };
+#endif
     /* First with the stack in LDS (bvh_stack_limit entries: no more than the tree can need, no more than
      * BDPT_BVH_STACK).  The lanes that ran over walk again, from the root, with BDPT_BVH_DEEP entries in their private
      * memory (rays that graze a fine mesh do; on a soup of 100 000 triangles none does), and whoever runs over there
      * too meets every triangle of the scene.  The comparison by (distance, index) makes a second meeting with a triangle
      * harmless. */
+#if BDPT_BVH_STEAL
+    /* sharing pays from some 8 000 triangles on (soups of 3 000 / 10 000 / 30 000 / 100 000 triangles, 16 samples at 1080p:
+     * 40.3 / 58.9 / 86 / 132 ms shared, 38.2 / 59.9 / 104 / 154 ms each lane for itself): the host decides */
+    bool overflow = S.bvh_share ? walk_shared()
+                                : walk([&](int at, int ref) { stack[at * 64] = (uint32_t)ref; }, [&](int at) { return (int)stack[at * 64]; }, S.bvh_stack_limit);
+#else
     bool overflow = walk([&](int at, int ref) { stack[at * 64] = (uint32_t)ref; }, [&](int at) { return (int)stack[at * 64]; }, S.bvh_stack_limit);
+#endif
     if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
         asm volatile("");                                                  /* a real branch: the second walk is rare */
         if (overflow) {
@@ -775,7 +956,7 @@ BDPT_DEV Hit trace_one(const bdpt_dev_scene &S, clm_f3 o, clm_f3 d, int otype, i
 #endif
     if (MODE == MODE_LDS2) return closest_hit_lds2<COUNT>(S, o, d, otype, oidx, &T.cull, &T.exact);
     if (MODE == MODE_BVH)                                   /* the lane's column of its wavefront's stack, at the start of LDS */
-        return closest_hit_bvh<COUNT>(S, (uint32_t *)bdpt_lds + (threadIdx.x >> 6) * (S.bvh_stack_limit * 64) + (threadIdx.x & 63), o, d, otype, oidx, &T.cull, &T.exact);
+        return closest_hit_bvh<COUNT>(S, (uint32_t *)bdpt_lds + (threadIdx.x >> 6) * (S.bvh_stack_limit * 64 + BDPT_BVH_SHARE_BYTES / 4) + (threadIdx.x & 63), o, d, otype, oidx, &T.cull, &T.exact);
     return MODE == MODE_LDS ? closest_hit_lds<SCATTERED>(S, o, d, otype, oidx) : closest_hit_direct(S, o, d, otype, oidx);
 }
 
@@ -1599,7 +1780,7 @@ static hipError_t launch_per_pixel(bdpt_kargs K, bool aov, bool count, hipStream
         if (K.scene.bvh_n_brute > 0 && !K.scene.bvh_brute) return hipErrorInvalidValue;
         if (K.scene.bvh_stack_limit < 1 || K.scene.bvh_stack_limit > BDPT_BVH_STACK) return hipErrorInvalidValue;
         if (K.scene.bvh_stack_total < K.scene.bvh_stack_limit || K.scene.bvh_stack_total > BDPT_BVH_DEEP) return hipErrorInvalidValue;
-        lds = (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t);        /* one wavefront per workgroup, its lanes' stacks */
+        lds = (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t) + BDPT_BVH_SHARE_BYTES;   /* one wavefront per workgroup: its lanes' stacks, what they share */
     }
     dim3 grid;
     const dim3 block(K.block);
@@ -1733,7 +1914,7 @@ static void class_pool_shape(const bdpt_kargs &K, int variant, int &block, size_
     const size_t pool = (size_t)BDPT_CPOOL_WAVE_F4 * sizeof(float4);
     if (variant == BDPT_KERNEL_DIRECT || variant == BDPT_KERNEL_BVH) {
         block = 64;
-        lds = pool + (variant == BDPT_KERNEL_BVH ? (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t) : 0);   /* the hierarchy walk's stacks come first */
+        lds = pool + (variant == BDPT_KERNEL_BVH ? (size_t)K.scene.bvh_stack_limit * 64 * sizeof(uint32_t) + BDPT_BVH_SHARE_BYTES : 0);   /* the hierarchy walk's stacks come first */
         return;
     }
     const size_t scene = bdpt_lds_scene_bytes(K.scene, variant == BDPT_KERNEL_LDS2);

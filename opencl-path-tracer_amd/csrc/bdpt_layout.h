@@ -89,6 +89,7 @@ struct bdpt_dev_scene {
     const uint32_t *bvh_brute;  /* [bvh_n_brute] triangles every ray tests in full, ascending */
     int bvh_root, bvh_n_brute;
     int bvh_stack_limit;        /* entries of the walk's per-lane stack in LDS, at most BDPT_BVH_STACK */
+    int bvh_share;              /* the lanes of a wavefront share the work of their walks (pays for large hierarchies) */
     int bvh_stack_total;        /* entries of the private-memory stack of a lane's second walk, at most BDPT_BVH_DEEP */
 };
 

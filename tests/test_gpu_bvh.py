@@ -14,7 +14,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("kind", bvh_scenes.KINDS)
 @pytest.mark.parametrize("n", [3, 400])
-def test_hierarchy_returns_the_reference_hit(bdpt, oracle, kind, n):
+@pytest.mark.parametrize("share", ["0", "1000000"])
+def test_hierarchy_returns_the_reference_hit(bdpt, oracle, monkeypatch, kind, n, share):
+    """share: hierarchies of this many triangles or more are walked with the lanes of a wavefront sharing work
+    (BDPT_BVH_SHARE_MIN, read when a context is created): always, never."""
+    monkeypatch.setenv("BDPT_BVH_SHARE_MIN", share)
     rng = np.random.default_rng(bvh_scenes.KINDS.index(kind) * 100 + n)
     scene = bvh_scenes.scene_for(bdpt, rng, kind, n)
     W, H = 48, 36
@@ -54,13 +58,15 @@ def test_equal_distances_go_to_the_lowest_index(bdpt, oracle):
 
 
 @pytest.mark.parametrize("limit", ["2", "2,64", "3,7"])
-def test_a_walk_whose_stack_runs_over(bdpt, oracle, monkeypatch, limit):
+@pytest.mark.parametrize("share", ["0", "1000000"])
+def test_a_walk_whose_stack_runs_over(bdpt, oracle, monkeypatch, limit, share):
     """A ray can pass all four boxes of node after node and need three stack entries per level; a lane whose LDS stack
     runs over walks again with a stack in its private memory, and if that runs over too it meets every triangle
     instead.  BDPT_BVH_STACK_LIMIT (read when a context is created) makes the stacks small enough for that to happen
     in nearly every search of this scene -- "2": both stacks two entries; "2,64": the second walk always succeeds;
     "3,7": some of each -- and every bit stays."""
     monkeypatch.setenv("BDPT_BVH_STACK_LIMIT", limit)
+    monkeypatch.setenv("BDPT_BVH_SHARE_MIN", share)
     rng = np.random.default_rng(21)
     scene = bvh_scenes.scene_for(bdpt, rng, "duplicates", 300)
     W, H = 40, 30
@@ -74,10 +80,11 @@ def test_a_walk_whose_stack_runs_over(bdpt, oracle, monkeypatch, limit):
 
 
 @pytest.mark.parametrize("flat", [False, True])
-def test_connected_mesh_with_shared_edges(bdpt, oracle, flat):
+def test_connected_mesh_with_shared_edges(bdpt, oracle, monkeypatch, flat):
     """3200 triangles that share every edge and vertex with neighbours of unrelated index (tests/bvh_scenes.py: mesh),
     seen from above by eye rays and from everywhere by connection and bounce rays: a ray through a shared edge or vertex
     gets equal distances from several triangles and must report the lowest index, as the reference's in-order walk does."""
+    monkeypatch.setenv("BDPT_BVH_SHARE_MIN", "0")           # lanes share work, as in scenes of many more triangles
     rng = np.random.default_rng(9)
     scene = bvh_scenes.mesh(bdpt, rng, 40, flat)
     W, H = 64, 48
